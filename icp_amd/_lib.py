@@ -1,0 +1,156 @@
+"""ctypes binding of libicp_hip.so (include/icp_hip.h) + device-buffer plumbing.
+
+PyTorch-ROCm is used only for device memory and streams: every call below hands
+raw device pointers (``tensor.data_ptr()``) and the current HIP stream to the
+C-ABI.  There is NO CPU fallback: if the shared library is missing or no GPU is
+visible the product path raises.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libicp_hip.so")
+
+ICP_COMPARE_SQRT = 1
+ICP_FORCE_BRUTE = 2
+
+c_dp = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_u32 = ctypes.c_uint32
+c_dbl = ctypes.c_double
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/icp_hip.h
+_SIGNATURES = {
+    "icp_version": [],
+    "icp_ctx_create": [c_int, ctypes.POINTER(ctypes.c_void_p)],
+    "icp_ctx_destroy": [c_dp],
+    "icp_ctx_set_stream": [c_dp, c_dp],
+    "icp_sync": [c_dp],
+    "icp_malloc": [c_dp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)],
+    "icp_free": [c_dp, c_dp],
+    "icp_memcpy_h2d": [c_dp, c_dp, c_dp, ctypes.c_size_t],
+    "icp_memcpy_d2h": [c_dp, c_dp, c_dp, ctypes.c_size_t],
+    "icp_closest": [c_dp, c_dp, c_i64, c_dp, c_i64, c_int, c_u32, c_dp, c_dp],
+    "icp_gather_points": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp],
+    "icp_distance_sum": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp],
+    "icp_find_transform": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_dp],
+    "icp_apply_transform": [c_dp, c_dp, c_i64, c_int, c_dp, c_dp, c_dp],
+    "icp_rigid_run": [c_dp, c_dp, c_i64, c_dp, c_i64, c_int, c_dbl, c_int, c_int, c_u32, c_dp, c_dp, c_dp, c_dp],
+    "icp_shard_sums": [c_dp, c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_dp, c_dp],
+    "icp_kabsch_solve": [c_dp, c_dp, c_int, c_dp, c_dp, c_dp, c_dp],
+    "icp_shard_apply_err": [c_dp, c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_dp, c_dp, c_dp],
+    "icp_column_sums": [c_dp, c_dp, c_i64, c_int, c_dp],
+}
+_RESTYPES = {"icp_last_error": ctypes.c_char_p}
+
+_lib = None
+_lock = threading.Lock()
+_ctxs = {}
+
+
+class IcpHipError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen libicp_hip.so and declare every symbol of include/icp_hip.h.
+    Raises if the library (or any symbol) is missing -- never falls back."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise IcpHipError(
+            "libicp_hip.so not found at %s -- build it with `make -C icp_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback" % p)
+    lib = ctypes.CDLL(p)
+    lib.icp_last_error.restype = ctypes.c_char_p
+    lib.icp_last_error.argtypes = []
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return ["icp_last_error"] + list(_SIGNATURES)
+
+
+def check(rc):
+    if rc != 0:
+        msg = load_library().icp_last_error()
+        raise IcpHipError("libicp_hip error %d: %s" % (rc, (msg or b"").decode()))
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise IcpHipError("no HIP device visible: icp_amd needs an AMD GPU (no CPU fallback)")
+    return torch
+
+
+class Context:
+    """One icp_ctx per device; tracks torch's current stream on every call."""
+
+    def __init__(self, device=None):
+        torch = _torch()
+        self.torch = torch
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        check(self.lib.icp_ctx_create(self.device, ctypes.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.icp_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def use_current_stream(self):
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.icp_ctx_set_stream(self.handle, ctypes.c_void_p(s)))
+
+    def call(self, name, *args):
+        self.use_current_stream()
+        check(getattr(self.lib, name)(self.handle, *args))
+
+    # -- buffers ---------------------------------------------------------
+    def to_dev(self, a, dtype=None):
+        """numpy array / torch tensor -> contiguous tensor on this device."""
+        torch = self.torch
+        if isinstance(a, torch.Tensor):
+            t = a
+            if dtype is not None and t.dtype != dtype:
+                t = t.to(dtype)
+            if not t.is_cuda:
+                t = t.cuda(self.device)
+            return t.contiguous()
+        arr = np.ascontiguousarray(a, dtype=np.float64 if dtype in (None, torch.float64) else np.int32)
+        return torch.from_numpy(arr).cuda(self.device)
+
+    def empty(self, shape, dtype=None):
+        torch = self.torch
+        return torch.empty(shape, dtype=dtype or torch.float64, device="cuda:%d" % self.device)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def get_context(device=None):
+    torch = _torch()
+    dev = torch.cuda.current_device() if device is None else int(device)
+    with _lock:
+        if dev not in _ctxs:
+            _ctxs[dev] = Context(dev)
+        return _ctxs[dev]

@@ -1,0 +1,77 @@
+// Internal helpers shared by the .hip translation units of libicp_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/icp_hip.h"
+
+namespace icp {
+
+void set_error(const char *fmt, ...);
+
+#define ICP_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            icp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,  \
+                           __LINE__);                                                        \
+            return ICP_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+#define ICP_REQUIRE(cond, msg)                              \
+    do {                                                    \
+        if (!(cond)) {                                      \
+            icp::set_error("%s: %s", __func__, msg);        \
+            return ICP_ERR_ARG;                             \
+        }                                                   \
+    } while (0)
+
+// Grow-only scratch buffer owned by the context.
+struct Scratch {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+constexpr int kMaxPartials = 2048;   // upper bound on blocks of any partial-sum reduction
+constexpr int kSumSlots = 16;        // doubles per block partial / per reduced vector
+
+}  // namespace icp
+
+struct icp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cu = 256;
+    icp::Scratch split_d2, split_idx;   // closest: per-split partial results
+    icp::Scratch partials;              // reductions: [kMaxPartials][kSumSlots] doubles
+    icp::Scratch small;                 // small fp64 state (sums, means, R, t, flags)
+    icp::Scratch work_a, work_b, work_c, work_d;  // general work arrays
+    icp::Scratch grid_a, grid_b, grid_c, grid_d, grid_e;  // spatial grid
+};
+
+namespace icp {
+int ensure(icp_ctx *ctx, Scratch &s, size_t bytes);
+
+// 64-bit shuffle helpers (wave = 64 lanes)
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_down_f64(double v, int delta) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_down(lo, delta, 64);
+    hi = __shfl_down(hi, delta, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += shfl_down_f64(v, o);
+    return v;  // valid in lane 0
+}
+}  // namespace icp

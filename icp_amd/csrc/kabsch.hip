@@ -1,0 +1,524 @@
+// Kabsch step, transform application, error metric and the fused rigid-ICP loop
+// (SURVEY.md section 8a rows a3, a4, a5).
+//
+// FindTransform (icp_3d.py:68-90) = column means + centred cross-covariance
+// W[a][b] = sum_i (nn_i[a]-tbar[a]) (s_i[b]-sbar[b]) + SVD.  On the GPU the sums are a
+// fixed-shape fp64 tree reduction (per-thread accumulators -> wave shuffle -> LDS ->
+// per-block partials -> one final block), so results are deterministic run to run.
+// To need only ONE pass over the points (and one all-reduce when sharded) the sums
+// are taken about fixed shifts cs, ct and corrected exactly:
+//     W = sum (nn-ct)(s-cs)^T - (1/N) sum(nn-ct) sum(s-cs)^T.
+// The 3x3 (2x2) SVD is a one-sided Jacobi iteration run by a single lane; the
+// reference applies no reflection fix (Q2) and neither does this.
+#include "common.h"
+
+namespace icp {
+
+int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
+                     unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done);
+
+constexpr int RB = 256;  // threads per reduction block
+
+// device-resident state of one fused ICP run
+struct RigidState {
+    double sums[kSumSlots];
+    double R[9];
+    double t[3];
+    double cs[3];
+    double ct[3];
+    double err;
+    double err_prev;
+    int32_t done;
+    int32_t iters;
+};
+
+template <int NS>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NS], double *__restrict__ out) {
+    __shared__ double red[RB / 64][NS];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const double v = wave_sum(acc[k]);
+        if ((tid & 63) == 0) red[tid >> 6][k] = v;
+    }
+    __syncthreads();
+    if (tid < NS) {
+        double v = red[0][tid];
+#pragma unroll
+        for (int w = 1; w < RB / 64; ++w) v += red[w][tid];
+        out[tid] = v;
+    }
+}
+
+// partial[b][0..15]: [sum(nn-ct) | sum(s-cs) | sum (nn-ct)(s-cs)^T | count]; nn = tgt[idx] or nn[i]
+template <int DIM, bool GATHER>
+__global__ __launch_bounds__(RB) void shard_sums_kernel(const double *__restrict__ src, const double *__restrict__ tgt,
+                                                        const int32_t *__restrict__ idx, int64_t n,
+                                                        const double *__restrict__ cs, const double *__restrict__ ct,
+                                                        double *__restrict__ partial, const int32_t *__restrict__ done) {
+    if (done && *done) return;
+    double acc[kSumSlots];
+#pragma unroll
+    for (int k = 0; k < kSumSlots; ++k) acc[k] = 0.0;
+    double c_s[DIM], c_t[DIM];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+        c_s[c] = cs[c];
+        c_t[c] = ct[c];
+    }
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += (int64_t)gridDim.x * RB) {
+        const int64_t j = GATHER ? (int64_t)idx[i] : i;
+        double s[DIM], t[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            s[c] = src[i * DIM + c] - c_s[c];
+            t[c] = tgt[j * DIM + c] - c_t[c];
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            acc[c] += t[c];
+            acc[3 + c] += s[c];
+        }
+#pragma unroll
+        for (int a = 0; a < DIM; ++a)
+#pragma unroll
+            for (int b = 0; b < DIM; ++b) acc[6 + a * DIM + b] += t[a] * s[b];
+        acc[15] += 1.0;
+    }
+    block_reduce_store<kSumSlots>(acc, partial + (int64_t)blockIdx.x * kSumSlots);
+}
+
+// column sums of one array -> slots 0..DIM-1, count in slot 15
+template <int DIM>
+__global__ __launch_bounds__(RB) void column_sums_kernel(const double *__restrict__ a, int64_t n,
+                                                         double *__restrict__ partial) {
+    double acc[kSumSlots];
+#pragma unroll
+    for (int k = 0; k < kSumSlots; ++k) acc[k] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += (int64_t)gridDim.x * RB) {
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) acc[c] += a[i * DIM + c];
+        acc[15] += 1.0;
+    }
+    block_reduce_store<kSumSlots>(acc, partial + (int64_t)blockIdx.x * kSumSlots);
+}
+
+// out[0..15] = sum_b partial[b][0..15], fixed summation tree; scale applied to slots < nscale
+__global__ __launch_bounds__(RB) void reduce_partials_kernel(const double *__restrict__ partial, int nb,
+                                                             double *__restrict__ out, int mean_slots,
+                                                             const int32_t *__restrict__ done) {
+    if (done && *done) return;
+    __shared__ double red[RB / kSumSlots][kSumSlots];
+    const int tid = threadIdx.x, slot = tid & (kSumSlots - 1), g = tid / kSumSlots;
+    double v = 0.0;
+    for (int b = g; b < nb; b += RB / kSumSlots) v += partial[(int64_t)b * kSumSlots + slot];
+    red[g][slot] = v;
+    __syncthreads();
+    if (tid < kSumSlots) {
+        double r = red[0][tid];
+        for (int k = 1; k < RB / kSumSlots; ++k) r += red[k][tid];
+        red[0][tid] = r;
+    }
+    __syncthreads();
+    if (tid < kSumSlots) {
+        double r = red[0][tid];
+        if (tid < mean_slots) r = r / red[0][15];  // column means (np.mean: sum / N)
+        out[tid] = r;
+    }
+}
+
+// One-sided Jacobi SVD of a DIMxDIM matrix; returns the reference's R = (U VT)^T = V U^T.
+template <int DIM>
+__device__ void polar_rotation(const double (&W)[DIM][DIM], double (&R)[DIM][DIM]) {
+    double A[DIM][DIM], V[DIM][DIM];
+    for (int a = 0; a < DIM; ++a)
+        for (int b = 0; b < DIM; ++b) {
+            A[a][b] = W[a][b];
+            V[a][b] = a == b ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < DIM - 1; ++p)
+            for (int q = p + 1; q < DIM; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int r = 0; r < DIM; ++r) {
+                    alpha += A[r][p] * A[r][p];
+                    beta += A[r][q] * A[r][q];
+                    gamma += A[r][p] * A[r][q];
+                }
+                if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+                for (int r = 0; r < DIM; ++r) {
+                    const double ap = A[r][p], aq = A[r][q];
+                    A[r][p] = c * ap - s * aq;
+                    A[r][q] = s * ap + c * aq;
+                    const double vp = V[r][p], vq = V[r][q];
+                    V[r][p] = c * vp - s * vq;
+                    V[r][q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    // U[:,j] = A[:,j]/sigma_j.  Rank-deficient W: the missing left vectors are completed to a
+    // right-handed frame (LAPACK's choice there is arbitrary; SURVEY.md section 7 "SVD degeneracy").
+    double U[DIM][DIM], sig[DIM], smax = 0;
+    for (int j = 0; j < DIM; ++j) {
+        double s2 = 0;
+        for (int r = 0; r < DIM; ++r) s2 += A[r][j] * A[r][j];
+        sig[j] = sqrt(s2);
+        smax = sig[j] > smax ? sig[j] : smax;
+    }
+    bool ok[DIM];
+    int nok = 0;
+    for (int j = 0; j < DIM; ++j) {
+        ok[j] = sig[j] > 1e-300 && sig[j] > 1e-14 * smax;
+        nok += ok[j];
+        for (int r = 0; r < DIM; ++r) U[r][j] = ok[j] ? A[r][j] / sig[j] : 0.0;
+    }
+    if (nok < DIM) {
+        if (DIM == 3 && nok == 2) {
+            int j = !ok[0] ? 0 : (!ok[1] ? 1 : 2), a = (j + 1) % 3, b = (j + 2) % 3;
+            // u_j = u_a x u_b and v_j = v_a x v_b would keep both frames right-handed; V is
+            // already orthonormal, so only U needs completing (sign follows det V).
+            double detV = V[0][0] * (V[1][1] * V[2][2] - V[1][2] * V[2][1]) - V[0][1] * (V[1][0] * V[2][2] - V[1][2] * V[2][0]) +
+                          V[0][2] * (V[1][0] * V[2][1] - V[1][1] * V[2][0]);
+            double sg = detV < 0 ? -1.0 : 1.0;
+            U[0][j] = sg * (U[1][a] * U[2][b] - U[2][a] * U[1][b]);
+            U[1][j] = sg * (U[2][a] * U[0][b] - U[0][a] * U[2][b]);
+            U[2][j] = sg * (U[0][a] * U[1][b] - U[1][a] * U[0][b]);
+        } else if (DIM == 2 && nok == 1) {
+            int j = ok[0] ? 1 : 0, a = 1 - j;
+            double detV = V[0][0] * V[1][1] - V[0][1] * V[1][0];
+            double sg = (detV < 0 ? -1.0 : 1.0) * (j == 1 ? 1.0 : -1.0);
+            U[0][j] = -sg * U[1][a];
+            U[1][j] = sg * U[0][a];
+        } else {
+            for (int a = 0; a < DIM; ++a)
+                for (int b = 0; b < DIM; ++b) U[a][b] = V[a][b];  // W ~ 0: R = I
+        }
+    }
+    for (int a = 0; a < DIM; ++a)
+        for (int b = 0; b < DIM; ++b) {
+            double r = 0;
+            for (int j = 0; j < DIM; ++j) r += V[a][j] * U[b][j];
+            R[a][b] = r;
+        }
+}
+
+template <int DIM>
+__global__ void kabsch_solve_kernel(const double *__restrict__ sums, const double *__restrict__ cs,
+                                    const double *__restrict__ ct, double *__restrict__ R_out,
+                                    double *__restrict__ t_out, const int32_t *__restrict__ done) {
+    if (done && *done) return;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double N = sums[15];
+    double sn[DIM], ss[DIM], tbar[DIM], sbar[DIM], W[DIM][DIM], R[DIM][DIM];
+    for (int c = 0; c < DIM; ++c) {
+        sn[c] = sums[c];
+        ss[c] = sums[3 + c];
+        tbar[c] = ct[c] + sn[c] / N;
+        sbar[c] = cs[c] + ss[c] / N;
+    }
+    for (int a = 0; a < DIM; ++a)
+        for (int b = 0; b < DIM; ++b) W[a][b] = sums[6 + a * DIM + b] - sn[a] * ss[b] / N;
+    polar_rotation<DIM>(W, R);
+    for (int a = 0; a < DIM; ++a)
+        for (int b = 0; b < DIM; ++b) R_out[a * DIM + b] = R[a][b];
+    for (int c = 0; c < DIM; ++c) {
+        double acc = 0;
+        for (int k = 0; k < DIM; ++k) acc += sbar[k] * R[k][c];
+        t_out[c] = tbar[c] - acc;
+    }
+}
+
+// ss = src R + t; partial err = sum ||nn - ss||  (icp_3d.py:113-114, 59-62)
+template <int DIM, int MODE>  // MODE 0: apply only; 1: apply + err vs tgt[idx]; 2: distance(a,b) only
+__global__ __launch_bounds__(RB) void apply_err_kernel(const double *__restrict__ src, const double *__restrict__ tgt,
+                                                       const int32_t *__restrict__ idx, int64_t n,
+                                                       const double *__restrict__ Rm, const double *__restrict__ tv,
+                                                       double *__restrict__ ss_out, double *__restrict__ partial,
+                                                       const int32_t *__restrict__ done) {
+    if (done && *done) return;
+    double R[DIM][DIM], t[DIM];
+    if (MODE != 2) {
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) {
+#pragma unroll
+            for (int b = 0; b < DIM; ++b) R[a][b] = Rm[a * DIM + b];
+            t[a] = tv[a];
+        }
+    }
+    double acc[1] = {0.0};
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += (int64_t)gridDim.x * RB) {
+        double s[DIM], o[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) s[c] = src[i * DIM + c];
+        if (MODE != 2) {
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                double v = s[0] * R[0][c];
+#pragma unroll
+                for (int k = 1; k < DIM; ++k) v += s[k] * R[k][c];
+                o[c] = v + t[c];
+                if (ss_out) ss_out[i * DIM + c] = o[c];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) o[c] = s[c];
+        }
+        if (MODE != 0) {
+            const int64_t j = MODE == 1 ? (int64_t)idx[i] : i;
+            double d2 = 0;
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                const double d = tgt[j * DIM + c] - o[c];
+                d2 += d * d;
+            }
+            acc[0] += sqrt(d2);
+        }
+    }
+    if (MODE != 0) block_reduce_store<1>(acc, partial + (int64_t)blockIdx.x * kSumSlots);
+}
+
+template <int DIM>
+__global__ void gather_kernel(const double *__restrict__ tgt, const int32_t *__restrict__ idx, int64_t n,
+                              double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t j = idx[i];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) out[i * DIM + c] = tgt[j * DIM + c];
+}
+
+__global__ void rigid_init_kernel(RigidState *st) {
+    st->err = 100000000.0;  // icp_3d.py:105
+    st->err_prev = 100000000.0;
+    st->done = 0;
+    st->iters = 0;
+}
+
+// end of one iteration: icp_3d.py:107,114-117
+__global__ void rigid_step_kernel(RigidState *st, double tol, int use_tol, double *err_hist) {
+    if (st->done) return;
+    const double e = st->err_prev;
+    const double err = st->sums[0];
+    st->err = err;
+    st->err_prev = err;
+    if (err_hist) err_hist[st->iters] = err;
+    st->iters += 1;
+    if (use_tol && (e - err) < tol) st->done = 1;
+}
+
+// icp_3d.py:118-121
+__global__ void rigid_finish_kernel(const RigidState *st, int dim, double *T, int32_t *iters_out) {
+    const int d1 = dim + 1;
+    for (int a = 0; a < d1; ++a)
+        for (int b = 0; b < d1; ++b) T[a * d1 + b] = a == b ? 1.0 : 0.0;
+    for (int a = 0; a < dim; ++a) {
+        for (int b = 0; b < dim; ++b) T[a * d1 + b] = st->R[a * dim + b];
+        T[dim * d1 + a] = st->t[a];
+    }
+    if (iters_out) *iters_out = st->iters;
+}
+
+static inline int nblocks_for(int64_t n) {
+    int64_t nb = (n + RB - 1) / RB;
+    if (nb > kMaxPartials) nb = kMaxPartials;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+static int reduce_to(icp_ctx *ctx, int nb, double *out_dev, int mean_slots, const int32_t *done) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(RB), 0, ctx->stream, (const double *)ctx->partials.ptr, nb,
+                       out_dev, mean_slots, done);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+static int shard_sums(icp_ctx *ctx, const double *src, const double *tgt, const int32_t *idx, int64_t n, int dim,
+                      const double *cs, const double *ct, double *sums_out, const int32_t *done) {
+    if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
+    const int nb = nblocks_for(n);
+    double *part = (double *)ctx->partials.ptr;
+    hipStream_t st = ctx->stream;
+    if (dim == 3) {
+        if (idx) hipLaunchKernelGGL((shard_sums_kernel<3, true>), dim3(nb), dim3(RB), 0, st, src, tgt, idx, n, cs, ct, part, done);
+        else hipLaunchKernelGGL((shard_sums_kernel<3, false>), dim3(nb), dim3(RB), 0, st, src, tgt, idx, n, cs, ct, part, done);
+    } else {
+        if (idx) hipLaunchKernelGGL((shard_sums_kernel<2, true>), dim3(nb), dim3(RB), 0, st, src, tgt, idx, n, cs, ct, part, done);
+        else hipLaunchKernelGGL((shard_sums_kernel<2, false>), dim3(nb), dim3(RB), 0, st, src, tgt, idx, n, cs, ct, part, done);
+    }
+    ICP_HIP_CHECK(hipGetLastError());
+    return reduce_to(ctx, nb, sums_out, 0, done);
+}
+
+static int column_sums(icp_ctx *ctx, const double *a, int64_t n, int dim, double *out, int mean) {
+    if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
+    const int nb = nblocks_for(n);
+    double *part = (double *)ctx->partials.ptr;
+    if (dim == 3) hipLaunchKernelGGL(column_sums_kernel<3>, dim3(nb), dim3(RB), 0, ctx->stream, a, n, part);
+    else hipLaunchKernelGGL(column_sums_kernel<2>, dim3(nb), dim3(RB), 0, ctx->stream, a, n, part);
+    ICP_HIP_CHECK(hipGetLastError());
+    return reduce_to(ctx, nb, out, mean ? dim : 0, nullptr);
+}
+
+static int kabsch_solve(icp_ctx *ctx, const double *sums, int dim, const double *cs, const double *ct, double *R,
+                        double *t, const int32_t *done) {
+    if (dim == 3) hipLaunchKernelGGL(kabsch_solve_kernel<3>, dim3(1), dim3(64), 0, ctx->stream, sums, cs, ct, R, t, done);
+    else hipLaunchKernelGGL(kabsch_solve_kernel<2>, dim3(1), dim3(64), 0, ctx->stream, sums, cs, ct, R, t, done);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+// mode 0 apply, 1 apply+err(gather), 2 distance
+static int apply_err(icp_ctx *ctx, int mode, const double *src, const double *tgt, const int32_t *idx, int64_t n,
+                     int dim, const double *R, const double *t, double *ss_out, double *err_out, const int32_t *done) {
+    if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
+    const int nb = nblocks_for(n);
+    double *part = (double *)ctx->partials.ptr;
+    hipStream_t st = ctx->stream;
+#define ICP_LAUNCH_AE(D, M) \
+    hipLaunchKernelGGL((apply_err_kernel<D, M>), dim3(nb), dim3(RB), 0, st, src, tgt, idx, n, R, t, ss_out, part, done)
+    if (dim == 3) {
+        if (mode == 0) ICP_LAUNCH_AE(3, 0);
+        else if (mode == 1) ICP_LAUNCH_AE(3, 1);
+        else ICP_LAUNCH_AE(3, 2);
+    } else {
+        if (mode == 0) ICP_LAUNCH_AE(2, 0);
+        else if (mode == 1) ICP_LAUNCH_AE(2, 1);
+        else ICP_LAUNCH_AE(2, 2);
+    }
+#undef ICP_LAUNCH_AE
+    ICP_HIP_CHECK(hipGetLastError());
+    if (mode == 0) return ICP_OK;
+    // only slot 0 of each partial row is written in this mode; the other slots hold stale
+    // numbers from earlier reductions and are ignored by the caller
+    return reduce_to(ctx, nb, err_out, 0, done);
+}
+
+}  // namespace icp
+
+using namespace icp;
+
+#define ICP_COMMON_ARGS(ctx, dim)                                \
+    ICP_REQUIRE(ctx != nullptr, "null context");                 \
+    ICP_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");     \
+    ICP_HIP_CHECK(hipSetDevice(ctx->device))
+
+extern "C" int icp_gather_points(icp_ctx *ctx, const double *tgt, const int32_t *idx, int64_t n, int dim, double *nn_out) {
+    ICP_COMMON_ARGS(ctx, dim);
+    ICP_REQUIRE(tgt && idx && nn_out && n >= 0, "bad argument");
+    if (n == 0) return ICP_OK;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (dim == 3) hipLaunchKernelGGL(gather_kernel<3>, dim3(nb), dim3(256), 0, ctx->stream, tgt, idx, n, nn_out);
+    else hipLaunchKernelGGL(gather_kernel<2>, dim3(nb), dim3(256), 0, ctx->stream, tgt, idx, n, nn_out);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+extern "C" int icp_distance_sum(icp_ctx *ctx, const double *a, const double *b, int64_t n, int dim, double *out_dev) {
+    ICP_COMMON_ARGS(ctx, dim);
+    ICP_REQUIRE(a && b && out_dev && n >= 0, "bad argument");
+    if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
+    double *tmp = (double *)ctx->small.ptr + 256;  // 16 scratch doubles
+    if (int rc = apply_err(ctx, 2, b, a, nullptr, n, dim, nullptr, nullptr, nullptr, tmp, nullptr)) return rc;
+    ICP_HIP_CHECK(hipMemcpyAsync(out_dev, tmp, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return ICP_OK;
+}
+
+extern "C" int icp_column_sums(icp_ctx *ctx, const double *a, int64_t n, int dim, double *out_dev) {
+    ICP_COMMON_ARGS(ctx, dim);
+    ICP_REQUIRE(a && out_dev && n > 0, "bad argument");
+    if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
+    double *tmp = (double *)ctx->small.ptr + 256;
+    if (int rc = column_sums(ctx, a, n, dim, tmp, 0)) return rc;
+    ICP_HIP_CHECK(hipMemcpyAsync(out_dev, tmp, sizeof(double) * dim, hipMemcpyDeviceToDevice, ctx->stream));
+    return ICP_OK;
+}
+
+extern "C" int icp_find_transform(icp_ctx *ctx, const double *src, const double *nn, int64_t n, int dim,
+                                  double *R_out_dev, double *t_out_dev) {
+    ICP_COMMON_ARGS(ctx, dim);
+    ICP_REQUIRE(src && nn && R_out_dev && t_out_dev && n > 0, "bad argument");
+    if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
+    double *base = (double *)ctx->small.ptr + 256;
+    double *cs = base + 16, *ct = base + 32, *sums = base + 48;
+    // pass 1: the two column means (icp_3d.py:69,71); pass 2: cross-covariance about them
+    if (int rc = column_sums(ctx, src, n, dim, cs, 1)) return rc;
+    if (int rc = column_sums(ctx, nn, n, dim, ct, 1)) return rc;
+    if (int rc = shard_sums(ctx, src, nn, nullptr, n, dim, cs, ct, sums, nullptr)) return rc;
+    return kabsch_solve(ctx, sums, dim, cs, ct, R_out_dev, t_out_dev, nullptr);
+}
+
+extern "C" int icp_apply_transform(icp_ctx *ctx, const double *src, int64_t n, int dim, const double *R_dev,
+                                   const double *t_dev, double *out) {
+    ICP_COMMON_ARGS(ctx, dim);
+    ICP_REQUIRE(src && R_dev && t_dev && out && n >= 0, "bad argument");
+    if (n == 0) return ICP_OK;
+    return apply_err(ctx, 0, src, nullptr, nullptr, n, dim, R_dev, t_dev, out, nullptr, nullptr);
+}
+
+extern "C" int icp_shard_sums(icp_ctx *ctx, const double *src, const double *tgt, const int32_t *idx, int64_t n,
+                              int dim, const double *cs_dev, const double *ct_dev, double *sums_out_dev) {
+    ICP_COMMON_ARGS(ctx, dim);
+    ICP_REQUIRE(src && tgt && idx && cs_dev && ct_dev && sums_out_dev && n >= 0, "bad argument");
+    return shard_sums(ctx, src, tgt, idx, n, dim, cs_dev, ct_dev, sums_out_dev, nullptr);
+}
+
+extern "C" int icp_kabsch_solve(icp_ctx *ctx, const double *sums_dev, int dim, const double *cs_dev,
+                                const double *ct_dev, double *R_out_dev, double *t_out_dev) {
+    ICP_COMMON_ARGS(ctx, dim);
+    ICP_REQUIRE(sums_dev && cs_dev && ct_dev && R_out_dev && t_out_dev, "null pointer");
+    return kabsch_solve(ctx, sums_dev, dim, cs_dev, ct_dev, R_out_dev, t_out_dev, nullptr);
+}
+
+extern "C" int icp_shard_apply_err(icp_ctx *ctx, const double *src, const double *tgt, const int32_t *idx, int64_t n,
+                                   int dim, const double *R_dev, const double *t_dev, double *ss_out, double *err_out_dev) {
+    ICP_COMMON_ARGS(ctx, dim);
+    ICP_REQUIRE(src && tgt && idx && R_dev && t_dev && err_out_dev && n >= 0, "bad argument");
+    if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
+    double *tmp = (double *)ctx->small.ptr + 256;
+    if (int rc = apply_err(ctx, 1, src, tgt, idx, n, dim, R_dev, t_dev, ss_out, tmp, nullptr)) return rc;
+    ICP_HIP_CHECK(hipMemcpyAsync(err_out_dev, tmp, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return ICP_OK;
+}
+
+extern "C" int icp_rigid_run(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
+                             double tol, int max_iter, int use_tol, unsigned flags, double *T_out_dev,
+                             double *err_hist_dev, int32_t *iters_out_dev, int32_t *idx_out) {
+    ICP_COMMON_ARGS(ctx, dim);
+    ICP_REQUIRE(src && tgt && T_out_dev, "null pointer");
+    ICP_REQUIRE(n > 0 && m > 0 && m < 0x7fffffff, "need n > 0 and 0 < m < 2^31");
+    ICP_REQUIRE(max_iter > 0, "run = 0 leaves R undefined (icp_3d.py:118-120)");
+    if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
+    if (int rc = ensure(ctx, ctx->work_c, (size_t)n * dim * sizeof(double))) return rc;
+    int32_t *idx = idx_out;
+    if (!idx) {
+        if (int rc = ensure(ctx, ctx->work_d, (size_t)n * sizeof(int32_t))) return rc;
+        idx = (int32_t *)ctx->work_d.ptr;
+    }
+    RigidState *st = (RigidState *)ctx->small.ptr;
+    double *ss = (double *)ctx->work_c.ptr;
+    hipStream_t s = ctx->stream;
+    hipLaunchKernelGGL(rigid_init_kernel, dim3(1), dim3(1), 0, s, st);
+    ICP_HIP_CHECK(hipGetLastError());
+    // iteration-invariant shifts: mean of the ORIGINAL source (Q1) and of the target
+    if (int rc = column_sums(ctx, src, n, dim, st->cs, 1)) return rc;
+    if (int rc = column_sums(ctx, tgt, m, dim, st->ct, 1)) return rc;
+    ICP_HIP_CHECK(hipMemcpyAsync(ss, src, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToDevice, s));  // icp_3d.py:104
+    const int32_t *done = &st->done;
+    for (int it = 0; it < max_iter; ++it) {
+        if (int rc = closest_dispatch(ctx, ss, n, tgt, m, dim, flags, idx, nullptr, done)) return rc;
+        if (int rc = shard_sums(ctx, src, tgt, idx, n, dim, st->cs, st->ct, st->sums, done)) return rc;
+        if (int rc = kabsch_solve(ctx, st->sums, dim, st->cs, st->ct, st->R, st->t, done)) return rc;
+        if (int rc = apply_err(ctx, 1, src, tgt, idx, n, dim, st->R, st->t, ss, st->sums, done)) return rc;
+        hipLaunchKernelGGL(rigid_step_kernel, dim3(1), dim3(1), 0, s, st, tol, use_tol, err_hist_dev);
+        ICP_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(rigid_finish_kernel, dim3(1), dim3(1), 0, s, (const RigidState *)st, dim, T_out_dev, iters_out_dev);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}

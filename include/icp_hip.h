@@ -1,0 +1,128 @@
+/*
+ * icp_hip.h -- C-ABI of libicp_hip.so: the MI355X (gfx950) implementation of the
+ * drawpixels/icp hot path (closest point, Kabsch step, NICP solve).
+ *
+ * The reference has no FFI seam of its own: its hot path is a set of module-level
+ * Python functions and private C++ methods.  Every entry
+ * point below therefore cites the reference function(s) it replaces; the Python
+ * mirror (the icp_amd Python modules) and the C++ nicp3d core (icp_amd/csrc/nicp3d_core.cpp)
+ * bind exactly these symbols.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error (icp_last_error() gives the
+ *    message of the calling thread's last failure); nothing throws across the ABI.
+ *  - all array pointers are DEVICE pointers to caller-owned fp64 / int32 buffers,
+ *    row-major [rows, dim] (AoS), dim in {2,3}; row-vector convention p' = p R + t.
+ *  - work is enqueued on the context's stream (icp_ctx_set_stream) and is
+ *    asynchronous unless stated; calls on one context must be serialised by the
+ *    caller; contexts are independent.
+ *  - the library frees nothing it did not allocate.
+ */
+#ifndef ICP_HIP_H
+#define ICP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct icp_ctx icp_ctx;
+typedef void *icp_stream; /* a hipStream_t */
+
+enum {
+    ICP_OK = 0,
+    ICP_ERR_ARG = -1,         /* bad argument (null pointer, dim not 2/3, n<=0 ...) */
+    ICP_ERR_HIP = -2,         /* a HIP runtime call failed */
+    ICP_ERR_NOMEM = -3,       /* scratch allocation failed */
+    ICP_ERR_UNSUPPORTED = -4, /* valid request this build cannot serve */
+    ICP_ERR_NUMERIC = -5      /* solver broke down (non-finite values) */
+};
+
+/* flags for icp_closest / icp_rigid_run */
+enum {
+    ICP_COMPARE_SQRT = 1u, /* nicp3d.cpp:56-63,142-164: compare rounded sqrt(d2) (Q12) */
+    ICP_FORCE_BRUTE = 2u   /* never use the spatial-grid search, always scan all targets */
+};
+
+const char *icp_last_error(void);
+int icp_version(void);
+
+/* context: owns scratch buffers and the stream for one device */
+int icp_ctx_create(int device, icp_ctx **out);
+int icp_ctx_destroy(icp_ctx *ctx);
+int icp_ctx_set_stream(icp_ctx *ctx, icp_stream stream);
+int icp_sync(icp_ctx *ctx);
+
+/* device-memory helpers for hosts that have no tensor library (the C++ nicp3d
+ * core); replaces TNT::Array1D/Array2D storage, tnt_array1d.h:38-85,
+ * tnt_array2d.h:36-79.  h2d/d2h are stream-ordered and synchronise before return. */
+int icp_malloc(icp_ctx *ctx, size_t bytes, void **dptr);
+int icp_free(icp_ctx *ctx, void *dptr);
+int icp_memcpy_h2d(icp_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int icp_memcpy_d2h(icp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---------------------------------------------------------------- rigid ICP */
+
+/* Closest / Match: icp_3d.py:39-42,48-53 (= icp_row.py:50-64, nicp_3d.py:62-77,
+ * nicp_row.py:75-89, nicp_row_rt.py:55-69, icp.py:18-21) and nicp3d.cpp:142-164,
+ * 259-272 with ICP_COMPARE_SQRT.  idx_out[i] = argmin_j ((dx*dx)+(dy*dy))+(dz*dz),
+ * fp64, no FMA, lowest index on ties, first NaN wins (np.argmin).  d2_out may be
+ * NULL. */
+int icp_closest(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
+                unsigned flags, int32_t *idx_out, double *d2_out);
+
+/* nn[i] = tgt[idx[i]]: the gather inside Match, icp_3d.py:52, nicp3d.cpp:266 */
+int icp_gather_points(icp_ctx *ctx, const double *tgt, const int32_t *idx, int64_t n, int dim,
+                      double *nn_out);
+
+/* Distance: icp_3d.py:59-62 -- sum_i ||a_i - b_i||_2 -> out_dev[0] */
+int icp_distance_sum(icp_ctx *ctx, const double *a, const double *b, int64_t n, int dim,
+                     double *out_dev);
+
+/* FindTransform: icp_3d.py:68-90 (icp_row.py:79-107 packs the same numbers into T;
+ * icp.py:59-74 is the transpose).  Kabsch, no scale, no reflection fix (Q2).
+ * R_out_dev[dim*dim] row-major, t_out_dev[dim]. */
+int icp_find_transform(icp_ctx *ctx, const double *src, const double *nn, int64_t n, int dim,
+                       double *R_out_dev, double *t_out_dev);
+
+/* ss = src R + t: icp_3d.py:113 */
+int icp_apply_transform(icp_ctx *ctx, const double *src, int64_t n, int dim, const double *R_dev,
+                        const double *t_dev, double *out);
+
+/* ICP: icp_3d.py:102-121 (use_tol=0: icp_row.py:112-143, Q4).  Runs up to max_iter
+ * iterations entirely on the device (no host round trip per iteration).
+ * T_out_dev[(dim+1)^2] row-vector homogeneous matrix; err_hist_dev[max_iter] (may be
+ * NULL) receives Distance(nn,ss) per executed iteration; iters_out_dev[0] = number of
+ * executed iterations; idx_out (may be NULL) = correspondences of the last executed
+ * iteration.  max_iter = 0 is an error like the reference's NameError (Q3). */
+int icp_rigid_run(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
+                  double tol, int max_iter, int use_tol, unsigned flags, double *T_out_dev,
+                  double *err_hist_dev, int32_t *iters_out_dev, int32_t *idx_out);
+
+/* Building blocks of one ICP iteration for source-sharded multi-GPU runs
+ * (SURVEY.md section 8e): every rank calls these on its shard and all-reduces (sum) the
+ * small fp64 vectors in between.
+ *   icp_shard_sums:  sums_out_dev[16] = [ sum(nn-ct) (3) | sum(s-cs) (3) |
+ *                    sum (nn-ct)^T (s-cs) (9, [a*dim+b], a indexes nn) | count ]
+ *                    with nn = tgt[idx]; cs_dev/ct_dev are dim-vectors of shifts
+ *                    (any value; the global source mean / target mean are good).
+ *                    For dim=2 the unused slots are 0.
+ *   icp_kabsch_solve: from (all-reduced) sums and the shifts -> R_out_dev, t_out_dev.
+ *   icp_shard_apply_err: ss = src R + t, err_out_dev[0] = sum_i ||tgt[idx_i]-ss_i||.
+ * Together they compute what FindTransform + icp_3d.py:113-114 compute. */
+int icp_shard_sums(icp_ctx *ctx, const double *src, const double *tgt, const int32_t *idx, int64_t n,
+                   int dim, const double *cs_dev, const double *ct_dev, double *sums_out_dev);
+int icp_kabsch_solve(icp_ctx *ctx, const double *sums_dev, int dim, const double *cs_dev,
+                     const double *ct_dev, double *R_out_dev, double *t_out_dev);
+int icp_shard_apply_err(icp_ctx *ctx, const double *src, const double *tgt, const int32_t *idx,
+                        int64_t n, int dim, const double *R_dev, const double *t_dev, double *ss_out,
+                        double *err_out_dev);
+/* column sums of a [n,dim] array -> out_dev[dim] (for the shifts above) */
+int icp_column_sums(icp_ctx *ctx, const double *a, int64_t n, int dim, double *out_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICP_HIP_H */

@@ -1,0 +1,227 @@
+"""GPU parity tests for the rigid-ICP path: HIP (through the C-ABI) vs the oracle.
+Indices must be bit-exact; transforms within 1e-6 relative (north_star)."""
+import numpy as np
+import pytest
+
+import icp_oracle as orc
+import c_oracle
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from icp_amd import rigid, icp_3d, icp_row, icp
+    from icp_amd._lib import get_context
+    return dict(rigid=rigid, icp_3d=icp_3d, icp_row=icp_row, icp=icp, ctx=get_context(), torch=torch)
+
+
+def gpu_idx(api, src, tgt, **kw):
+    out = api["rigid"].closest_indices(src, tgt, **kw)
+    if isinstance(out, tuple):
+        return out[0].cpu().numpy(), out[1].cpu().numpy()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["closest_1k_normal3", "closest_20_50_dim2", "closest_ties3", "closest_nearties3"])
+def test_match_golden(api, name):
+    g = golden(name)
+    idx, d2 = gpu_idx(api, g["src"], g["tgt"], want_d2=True)
+    assert np.array_equal(idx, g["idx"])
+    oi, od2 = orc.match_idx(g["src"], g["tgt"])
+    assert np.array_equal(d2, od2)          # the squared distances are bit-exact too
+    nn = api["icp_3d"].Match(g["src"], g["tgt"])
+    assert np.array_equal(nn, g["tgt"][g["idx"]])
+
+
+def test_match_golden_4k_50k(api):
+    g = golden("closest_4k_50k_uniform3")
+    rng = np.random.default_rng(int(g["seed"]))
+    src = rng.uniform(-1, 1, (4096, 3))
+    tgt = rng.uniform(-1, 1, (50000, 3))
+    assert np.array_equal(gpu_idx(api, src, tgt), g["idx"])
+
+
+def test_closest_single_and_col(api):
+    g = golden("closest_1k_normal3")
+    for i in (0, 17, 999):
+        assert api["icp_3d"].Closest(g["tgt"], g["src"][i]) == int(g["idx"][i])
+    g = golden("closest_col2")
+    for i in range(g["src"].shape[1]):
+        assert api["icp"].closest(g["tgt"], g["src"][:, i:i + 1]) == int(g["idx"][i])
+
+
+# (n, m, dim): exercises the lanes kernel (small n), the tile kernel with Q=1/2/4, target
+# splits, ragged tails (m not a multiple of the tile / chunk) and m < one tile
+@pytest.mark.parametrize("n,m,dim", [(1, 1, 3), (3, 5, 2), (1, 100003, 3), (257, 4099, 3), (1000, 1000, 3),
+                                     (20000, 3001, 3), (20000, 5, 2), (70001, 2049, 2),
+                                     (300000, 1027, 3), (600000, 515, 3), (1100000, 260, 3)])
+def test_match_vs_c_oracle(api, n, m, dim):
+    rng = np.random.default_rng(n * 7 + m)
+    src = rng.standard_normal((n, dim))
+    tgt = rng.standard_normal((m, dim))
+    idx, d2 = gpu_idx(api, src, tgt, want_d2=True)
+    oi, od = c_oracle.match_idx(src, tgt)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(d2, od)
+
+
+def test_match_duplicates_lowest_index(api):
+    rng = np.random.default_rng(5)
+    base = rng.integers(-3, 4, (200, 3)).astype(np.float64)     # heavy duplication
+    tgt = np.concatenate([base, base, base])[rng.permutation(600)]
+    src = rng.integers(-3, 4, (30000, 3)).astype(np.float64) + 0.5
+    idx = gpu_idx(api, src, tgt)
+    oi, _ = c_oracle.match_idx(src, tgt)
+    assert np.array_equal(idx, oi)
+    idx1 = gpu_idx(api, src[:100], tgt)                          # lanes kernel
+    assert np.array_equal(idx1, oi[:100])
+
+
+def test_match_nan_inf(api):
+    rng = np.random.default_rng(6)
+    tgt = rng.standard_normal((3000, 3))
+    tgt[1234, 1] = np.nan
+    tgt[2000, 0] = np.nan
+    src = rng.standard_normal((20000, 3))
+    expect = np.full(20000, 1234)                                # np.argmin: first NaN wins
+    assert np.array_equal(gpu_idx(api, src, tgt), expect)
+    assert np.array_equal(gpu_idx(api, src[:10], tgt), expect[:10])
+    assert orc.closest(tgt, src[0]) == 1234
+    tgt = np.full((2000, 3), 1e200)                              # every d2 overflows to +inf -> index 0
+    assert np.array_equal(gpu_idx(api, src, tgt), np.zeros(20000))
+    assert np.array_equal(gpu_idx(api, src[:7], tgt), np.zeros(7))
+
+
+def test_compare_sqrt_mode(api):
+    # d2 differs by one ulp but the rounded roots tie: numpy picks the smaller d2 (index 1),
+    # nicp3d.cpp's sqrt compare keeps the earlier index 0 (Q12)
+    tgt = np.array([[1.0, 2.0 ** -26, 0.0], [1.0, 0.0, 0.0], [5.0, 5.0, 5.0]])
+    q = np.zeros((1, 3))
+    assert orc.closest(tgt, q[0]) == 1 and orc.closest(tgt, q[0], compare_sqrt=True) == 0
+    assert gpu_idx(api, q, tgt)[0] == 1
+    assert gpu_idx(api, q, tgt, compare_sqrt=True)[0] == 0
+    rng = np.random.default_rng(8)
+    tgt = np.concatenate([rng.standard_normal((5000, 3)), tgt])
+    src = np.concatenate([rng.standard_normal((20000, 3)) * 1e-9, rng.standard_normal((100, 3))])
+    oi, _ = c_oracle.match_idx(src, tgt, compare_sqrt=True)
+    assert np.array_equal(gpu_idx(api, src, tgt, compare_sqrt=True), oi)
+    assert np.array_equal(gpu_idx(api, src[-50:], tgt, compare_sqrt=True), oi[-50:])
+
+
+def test_empty_and_errors(api):
+    from icp_amd._lib import IcpHipError
+    tgt = np.zeros((4, 3))
+    assert gpu_idx(api, np.zeros((0, 3)), tgt).shape == (0,)
+    with pytest.raises(ValueError):
+        gpu_idx(api, np.zeros((2, 3)), np.zeros((0, 3)))
+    with pytest.raises(ValueError):
+        gpu_idx(api, np.zeros((2, 3)), np.zeros((4, 2)))
+    with pytest.raises(NameError):
+        api["icp_3d"].ICP(np.zeros((3, 3)), tgt, 0.1, 0)
+
+
+def test_distance_and_kabsch_golden(api):
+    g = golden("kabsch_3d")
+    R, t = api["icp_3d"].FindTransform(g["src"], g["nn"])
+    np.testing.assert_allclose(R, g["R"], rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(t, g["t"], rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(api["icp_3d"].Distance(g["src"], g["nn"]), float(g["dist"]), rtol=1e-12)
+    g = golden("kabsch_2d_T")
+    np.testing.assert_allclose(api["icp_row"].FindTransform(g["src"], g["nn"]), g["T"], rtol=RTOL, atol=1e-9)
+    g = golden("kabsch_3d_reflect")                                # Q2: no reflection fix
+    R, t = api["icp_3d"].FindTransform(g["src"], g["nn"])
+    np.testing.assert_allclose(R, g["R"], rtol=RTOL, atol=1e-9)
+    assert np.linalg.det(R) < 0
+
+
+@pytest.mark.parametrize("n,dim", [(3, 3), (4, 2), (100000, 3), (1 << 20, 3)])
+def test_kabsch_vs_oracle(api, n, dim):
+    rng = np.random.default_rng(n + dim)
+    s = rng.standard_normal((n, dim)) + 5.0            # off-centre: exercises the shifted sums
+    Rt = orc.rot_matrix(0.3, 0.2, -0.4) if dim == 3 else orc.rot2(0.7)
+    t = s @ Rt + rng.standard_normal(dim) + 1e-3 * rng.standard_normal((n, dim))
+    R, tv = api["icp_3d"].FindTransform(s, t)
+    Ro, to = c_oracle.find_transform(s, t)
+    np.testing.assert_allclose(R, Ro, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(tv, to, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(api["icp_3d"].Distance(s, t), orc.distance(s, t), rtol=1e-10)
+
+
+def test_icp_c1_golden(api):
+    g = golden("icp_c1")
+    src, tgt = orc.make_rigid_cloud(int(g["n"]), seed=int(g["seed"]))
+    r = api["rigid"].rigid_icp(src, tgt, float(g["tol"]), int(g["run"]), want_idx=True)
+    iters = int(r["iters"].cpu()[0])
+    assert iters == g["idx_hist"].shape[0]
+    np.testing.assert_allclose(r["err_hist"].cpu().numpy()[:iters], g["err_hist"], rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(r["T"].cpu().numpy(), g["T"], rtol=RTOL, atol=1e-9)
+    assert np.array_equal(r["idx"].cpu().numpy(), g["idx_hist"][-1])
+    T = api["icp_3d"].ICP(src, tgt, float(g["tol"]), int(g["run"]))
+    np.testing.assert_allclose(T, g["T"], rtol=RTOL, atol=1e-9)
+
+
+def test_icp_forced_and_row_golden(api):
+    g = golden("icp_forced30")
+    r = api["rigid"].rigid_icp(g["src"], g["tgt"], -np.inf, 30)
+    assert int(r["iters"].cpu()[0]) == 30
+    np.testing.assert_allclose(r["T"].cpu().numpy(), g["T"], rtol=RTOL, atol=1e-9)
+    g = golden("icp_row_demo")
+    T = api["icp_row"].ICP(g["src"], g["tgt"], 0.1, 20)
+    np.testing.assert_allclose(T, g["T"], rtol=RTOL, atol=1e-9)
+
+
+def test_icp_col_step(api):
+    g = golden("closest_col2")
+    nn, R, t, moved = api["icp"].icp_step(g["src"], g["tgt"])
+    onn, oR, ot, omoved = orc.icp_col_step(g["src"], g["tgt"])
+    assert np.array_equal(nn, onn)
+    np.testing.assert_allclose(R, oR, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(t, ot, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(moved, omoved, rtol=RTOL, atol=1e-9)
+
+
+def test_icp_100k_iteration_parity(api):
+    """Each GPU iteration checked against the oracle on the SAME inputs (the moved
+    source the GPU produced), so index parity is exact by construction."""
+    n = 100000
+    src, tgt = orc.make_rigid_cloud(n, seed=3)
+    rigid, torch = api["rigid"], api["torch"]
+    ctx = api["ctx"]
+    s_d, t_d = ctx.to_dev(src), ctx.to_dev(tgt)
+    ss = s_d.clone()
+    for it in range(3):
+        idx = rigid.closest_indices(ss, t_d)
+        oi, _ = c_oracle.match_idx(ss.cpu().numpy(), tgt)
+        assert np.array_equal(idx.cpu().numpy(), oi)
+        nn = rigid.gather_points(t_d, idx)
+        R, t = rigid.find_transform(s_d, nn)
+        Ro, to = c_oracle.find_transform(src, tgt[oi])
+        np.testing.assert_allclose(R.cpu().numpy(), Ro, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(t.cpu().numpy(), to, rtol=RTOL, atol=1e-9)
+        ss = rigid.apply_transform(s_d, R, t)
+        np.testing.assert_allclose(ss.cpu().numpy(), src @ Ro + to, rtol=RTOL, atol=1e-9)
+    r = rigid.rigid_icp(s_d, t_d, -np.inf, 3)
+    np.testing.assert_allclose(r["T"].cpu().numpy()[:3, :3], R.cpu().numpy(), rtol=1e-12, atol=1e-14)
+
+
+def test_match_full_size_properties(api):
+    """BASELINE config C2 size (2^20 x 2^20): checked through size-independent properties
+    -- a permuted copy matches itself exactly (d2 == 0, idx == inverse permutation), and a
+    random sample of rows agrees with the C oracle."""
+    n = 1 << 20
+    rng = np.random.default_rng(1)
+    tgt = rng.standard_normal((n, 3))
+    perm = rng.permutation(n)
+    idx, d2 = gpu_idx(api, tgt[perm], tgt, want_d2=True)
+    assert np.array_equal(idx, perm) and not d2.any()
+    src, _ = orc.make_rigid_cloud(n, seed=1)
+    idx = gpu_idx(api, src, tgt)
+    rows = rng.choice(n, 2048, replace=False)
+    oi, _ = c_oracle.match_idx(src[rows], tgt)
+    assert np.array_equal(idx[rows], oi)
