@@ -103,9 +103,10 @@ __global__ __launch_bounds__(RB) void column_sums_kernel(const double *__restric
     block_reduce_store<kSumSlots>(acc, partial + (int64_t)blockIdx.x * kSumSlots);
 }
 
-// out[0..15] = sum_b partial[b][0..15], fixed summation tree; scale applied to slots < nscale
+// out[0..nout-1] = sum_b partial[b][0..nout-1], fixed summation tree; slots < mean_slots are
+// divided by the count in slot 15 (np.mean: sum / N)
 __global__ __launch_bounds__(RB) void reduce_partials_kernel(const double *__restrict__ partial, int nb,
-                                                             double *__restrict__ out, int mean_slots,
+                                                             double *__restrict__ out, int nout, int mean_slots,
                                                              const int32_t *__restrict__ done) {
     if (done && *done) return;
     __shared__ double red[RB / kSumSlots][kSumSlots];
@@ -122,8 +123,8 @@ __global__ __launch_bounds__(RB) void reduce_partials_kernel(const double *__res
     __syncthreads();
     if (tid < kSumSlots) {
         double r = red[0][tid];
-        if (tid < mean_slots) r = r / red[0][15];  // column means (np.mean: sum / N)
-        out[tid] = r;
+        if (tid < mean_slots) r = r / red[0][15];
+        if (tid < nout) out[tid] = r;
     }
 }
 
@@ -331,9 +332,9 @@ static inline int nblocks_for(int64_t n) {
     return (int)nb;
 }
 
-static int reduce_to(icp_ctx *ctx, int nb, double *out_dev, int mean_slots, const int32_t *done) {
+static int reduce_to(icp_ctx *ctx, int nb, double *out_dev, int nout, int mean_slots, const int32_t *done) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(RB), 0, ctx->stream, (const double *)ctx->partials.ptr, nb,
-                       out_dev, mean_slots, done);
+                       out_dev, nout, mean_slots, done);
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
 }
@@ -352,7 +353,7 @@ static int shard_sums(icp_ctx *ctx, const double *src, const double *tgt, const 
         else hipLaunchKernelGGL((shard_sums_kernel<2, false>), dim3(nb), dim3(RB), 0, st, src, tgt, idx, n, cs, ct, part, done);
     }
     ICP_HIP_CHECK(hipGetLastError());
-    return reduce_to(ctx, nb, sums_out, 0, done);
+    return reduce_to(ctx, nb, sums_out, kSumSlots, 0, done);
 }
 
 static int column_sums(icp_ctx *ctx, const double *a, int64_t n, int dim, double *out, int mean) {
@@ -362,7 +363,7 @@ static int column_sums(icp_ctx *ctx, const double *a, int64_t n, int dim, double
     if (dim == 3) hipLaunchKernelGGL(column_sums_kernel<3>, dim3(nb), dim3(RB), 0, ctx->stream, a, n, part);
     else hipLaunchKernelGGL(column_sums_kernel<2>, dim3(nb), dim3(RB), 0, ctx->stream, a, n, part);
     ICP_HIP_CHECK(hipGetLastError());
-    return reduce_to(ctx, nb, out, mean ? dim : 0, nullptr);
+    return reduce_to(ctx, nb, out, dim, mean ? dim : 0, nullptr);
 }
 
 static int kabsch_solve(icp_ctx *ctx, const double *sums, int dim, const double *cs, const double *ct, double *R,
@@ -394,9 +395,8 @@ static int apply_err(icp_ctx *ctx, int mode, const double *src, const double *tg
 #undef ICP_LAUNCH_AE
     ICP_HIP_CHECK(hipGetLastError());
     if (mode == 0) return ICP_OK;
-    // only slot 0 of each partial row is written in this mode; the other slots hold stale
-    // numbers from earlier reductions and are ignored by the caller
-    return reduce_to(ctx, nb, err_out, 0, done);
+    // only slot 0 of each partial row is written in this mode
+    return reduce_to(ctx, nb, err_out, 1, 0, done);
 }
 
 }  // namespace icp

@@ -140,7 +140,7 @@ def test_distance_and_kabsch_golden(api):
     assert np.linalg.det(R) < 0
 
 
-@pytest.mark.parametrize("n,dim", [(3, 3), (4, 2), (100000, 3), (1 << 20, 3)])
+@pytest.mark.parametrize("n,dim", [(10, 3), (4, 2), (100000, 3), (1 << 20, 3)])
 def test_kabsch_vs_oracle(api, n, dim):
     rng = np.random.default_rng(n + dim)
     s = rng.standard_normal((n, dim)) + 5.0            # off-centre: exercises the shifted sums
@@ -151,6 +151,20 @@ def test_kabsch_vs_oracle(api, n, dim):
     np.testing.assert_allclose(R, Ro, rtol=RTOL, atol=1e-9)
     np.testing.assert_allclose(tv, to, rtol=RTOL, atol=1e-9)
     np.testing.assert_allclose(api["icp_3d"].Distance(s, t), orc.distance(s, t), rtol=1e-10)
+
+
+def test_kabsch_rank_deficient(api):
+    """3 points in 3-D: the centred cloud is planar, W has rank 2 and U VT is not unique
+    (LAPACK may return a reflection, the Jacobi path completes a right-handed frame;
+    SURVEY.md section 7 'SVD degeneracy', parity unpinned).  What IS determined -- the moved
+    source points -- must still agree."""
+    rng = np.random.default_rng(6)
+    s = rng.standard_normal((3, 3)) + 5.0
+    t = s @ orc.rot_matrix(0.3, 0.2, -0.4) + rng.standard_normal(3)
+    R, tv = api["icp_3d"].FindTransform(s, t)
+    Ro, to = c_oracle.find_transform(s, t)
+    np.testing.assert_allclose(s @ R + tv, s @ Ro + to, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(R @ R.T, np.identity(3), atol=1e-12)
 
 
 def test_icp_c1_golden(api):
