@@ -44,7 +44,31 @@ _SIGNATURES = {
     "icp_kabsch_solve": [c_dp, c_dp, c_int, c_dp, c_dp, c_dp, c_dp],
     "icp_shard_apply_err": [c_dp, c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_dp, c_dp, c_dp],
     "icp_column_sums": [c_dp, c_dp, c_i64, c_int, c_dp],
+    "nicp_knn": [c_dp, c_dp, c_i64, c_int, c_dp, c_i64, c_int, c_dp, c_dp],
+    "nicp_knn_weights": [c_dp, c_dp, c_i64, c_int, c_int, c_dp, c_dp],
+    "nicp_graph_create": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_i64, c_int, ctypes.POINTER(ctypes.c_void_p)],
+    "nicp_graph_destroy": [c_dp, c_dp],
+    "nicp_deform": [c_dp, c_dp, c_dp, c_dp, c_dp],
+    "nicp_residual": [c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_dp],
+    "nicp_jvp": [c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_dp, c_dp],
+    "nicp_jtvp": [c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_dp, c_dp],
+    "nicp_solve": [c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_dp, c_dp],
 }
+
+
+class SolveOpts(ctypes.Structure):
+    """nicp_solve_opts of include/icp_hip.h"""
+    _fields_ = [("ftol", c_dbl), ("xtol", c_dbl), ("gtol", c_dbl), ("lambda0", c_dbl), ("cg_tol", c_dbl),
+                ("max_lm_iters", c_int), ("max_cg_iters", c_int)]
+
+
+class SolveStats(ctypes.Structure):
+    """nicp_solve_stats of include/icp_hip.h"""
+    _fields_ = [("err", c_dbl), ("err0", c_dbl), ("lm_iters", c_int), ("cg_iters", c_int), ("nfev", c_int),
+                ("info", c_int)]
+
+
+NICP_REFERENCE_COMPAT = 1
 _RESTYPES = {"icp_last_error": ctypes.c_char_p}
 
 _lib = None

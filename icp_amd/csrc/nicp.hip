@@ -1,0 +1,1094 @@
+// Non-rigid ICP (embedded deformation) on the GPU: KNN influence weights, Deform,
+// residual, matrix-free Jacobian products and a Levenberg-Marquardt solver whose
+// linear systems (J^T J + lambda D^2) delta = -J^T r are solved by preconditioned
+// conjugate gradients.
+//
+// Parameter vector P (nicp_3d.py:154-156,171-175; 2-D: nicp_row.py:98,118-119):
+//   per vertex j: A_j (DIMxDIM row-major), b_j (DIM)          -> S = DIM*DIM+DIM numbers
+//   tail: Euler angles (3, or 1 in 2-D) then translation (DIM) -> NG numbers
+// Residual rows (nicp_3d.py:239-267): [c_fit*(nn - Deform) (DIM*N) | c_rigid*e_rigid
+// (NRIG*N) | c_smooth*e_smooth (2*DIM*E)].
+//
+// The reference's dense N x N weight matrix w (4 non-zeros per column) is stored as
+// nbr[N,K] / wt[N,K]: w[nbr[i,k], i] = wt[i,k]; its dense (9N+6E) x (12N+6) Jacobian is
+// never formed: J p and J^T u are gathered per vertex / per edge (reverse adjacency in
+// CSR form, built once per mesh), so every product is deterministic (no atomics).
+//
+// NICP_REFERENCE_COMPAT reproduces the reference's latent quirks:
+//   Q5 (3-D) rigid residual of vertex i written at slot 3i (the Jacobian rows stay at 6i),
+//   Q6 global-rotation Jacobian columns use the already transformed points,
+//   Q7 (2-D) b-columns of the fit block carry no weight factor.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+struct nicp_graph {
+    int64_t n = 0, e = 0;
+    int dim = 3, k = 4;
+    int32_t *nbr = nullptr;      // [n,k]
+    double *wt = nullptr;        // [n,k]
+    int32_t *edges = nullptr;    // [e,2]
+    int32_t *rev_ptr = nullptr;  // [n+1]  reverse KNN adjacency: entries i*k+kk with nbr[i,kk]==j
+    int32_t *rev_ent = nullptr;  // [n*k]
+    int32_t *inc_ptr = nullptr;  // [n+1]  incident edges: entries e*2+end
+    int32_t *inc_ent = nullptr;  // [2e]
+    // solver workspace (grow-once)
+    double *ws = nullptr;
+    size_t ws_doubles = 0;
+};
+
+namespace icp {
+
+constexpr int NB = 256;
+constexpr int KNN_TILE = 512;
+
+template <int DIM>
+struct Lay {
+    static constexpr int NA = DIM * DIM;
+    static constexpr int S = DIM * DIM + DIM;
+    static constexpr int NANG = DIM == 3 ? 3 : 1;
+    static constexpr int NG = NANG + DIM;
+    static constexpr int NRIG = DIM == 3 ? 6 : 3;
+};
+
+// rotation + derivatives + translation, rebuilt from the tail of P
+struct Globals {
+    double R[9];
+    double dR[3][9];
+    double T[3];
+};
+
+// ------------------------------------------------------------------ KNN + weights
+// Exact k-nearest by the key the reference sorts on, sqrt(d2) (nicp_3d.py:53-57), with
+// ties resolved to the lower index (the C++ heap's rule, nicp3d.cpp:116-125, and what a
+// stable sort gives).  sqrt is only evaluated for candidates that can enter the list:
+// d2 > (largest d2 whose rounded root equals the current k-th root) is rejected first.
+template <int DIM, int K>
+__global__ __launch_bounds__(NB) void knn_rows_kernel(const double *__restrict__ v, int64_t n,
+                                                     const double *__restrict__ q, int64_t nq,
+                                                     int32_t *__restrict__ idx_out, double *__restrict__ dist_out) {
+    __shared__ double tile[KNN_TILE * DIM];
+    const int tid = threadIdx.x;
+    const int64_t qi = (int64_t)blockIdx.x * NB + tid;
+    const int64_t qq = qi < nq ? qi : nq - 1;
+    double s[DIM];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) s[c] = q[qq * DIM + c];
+    double key[K];
+    int32_t id[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        key[k] = __builtin_inf();
+        id[k] = 0x7fffffff;
+    }
+    double gate = __builtin_inf();  // reject d2 > gate without a sqrt
+    for (int64_t base = 0; base < n; base += KNN_TILE) {
+        const int cnt = (n - base) < KNN_TILE ? (int)(n - base) : KNN_TILE;
+        __syncthreads();
+        for (int e = tid; e < cnt * DIM; e += NB) tile[e] = v[base * DIM + e];
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            double d2 = 0.0;
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                const double d = tile[j * DIM + c] - s[c];
+                d2 += d * d;
+            }
+            if (!(d2 <= gate)) continue;
+            const double r = __dsqrt_rn(d2);
+            const int32_t jj = (int32_t)(base + j);
+            if (!(r < key[K - 1])) continue;  // ascending scan: an equal root with a higher index loses
+            // insert (r, jj) keeping (key, id) sorted ascending, stable
+            double ck = r;
+            int32_t ci = jj;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const bool sw = ck < key[k];
+                const double tk = sw ? key[k] : ck;
+                const int32_t ti = sw ? id[k] : ci;
+                key[k] = sw ? ck : key[k];
+                id[k] = sw ? ci : id[k];
+                ck = tk;
+                ci = ti;
+            }
+            // new gate: sqrt_rn(fl(kr*kr)) == kr, and sqrt is monotone, so every d2 whose root is
+            // below kr is below fl(kr*kr) (guarded against under/overflow of the square)
+            const double kr = key[K - 1];
+            gate = (kr > 1e-150 && kr < 1e150) ? kr * kr : __builtin_inf();
+        }
+    }
+    if (qi < nq) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            idx_out[qi * K + k] = id[k];
+            dist_out[qi * K + k] = key[k];
+        }
+    }
+}
+
+// weights from the K+2 nearest (nicp_3d.py:160-164 / nicp3d.cpp:208-214)
+template <int NN>
+__global__ void knn_weights_kernel(const int32_t *__restrict__ kidx, const double *__restrict__ kdist, int64_t n,
+                                   int32_t *__restrict__ nbr, double *__restrict__ wt) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    constexpr int K = NN + 2;
+    const double dmax = kdist[j * K + K - 1];
+    double sum = 0.0;
+    for (int i = 1; i <= NN; ++i) sum += kdist[j * K + i];
+    const double denom = (double)NN - sum / dmax;
+    for (int i = 1; i <= NN; ++i) {
+        nbr[j * NN + i - 1] = kidx[j * K + i];
+        wt[j * NN + i - 1] = (1.0 - kdist[j * K + i] / dmax) / denom;
+    }
+}
+
+// ------------------------------------------------------------------ globals
+template <int DIM>
+__global__ void globals_kernel(const double *__restrict__ P, int64_t n, Globals *__restrict__ g) {
+    if (threadIdx.x || blockIdx.x) return;
+    const double *tail = P + n * Lay<DIM>::S;
+    for (int k = 0; k < 9; ++k) {
+        g->R[k] = 0;
+        g->dR[0][k] = g->dR[1][k] = g->dR[2][k] = 0;
+    }
+    g->T[0] = g->T[1] = g->T[2] = 0;
+    if (DIM == 3) {
+        // nicp_3d.py:180-215 (rotation sequence X, Y, Z; row-vector convention)
+        const double sx = sin(tail[0]), cx = cos(tail[0]), sy = sin(tail[1]), cy = cos(tail[1]);
+        const double sz = sin(tail[2]), cz = cos(tail[2]);
+        const double R[9] = {cy * cz, cy * sz, -sy, sx * sy * cz - cx * sz, sx * sy * sz + cx * cz, sx * cy,
+                             cx * sy * cz + sx * sz, cx * sy * sz - sx * cz, cx * cy};
+        const double dx[9] = {0, 0, 0, cx * sy * cz + sx * sz, cx * sy * sz - sx * cz, cx * cy,
+                              -sx * sy * cz + cx * sz, -sx * sy * sz - cx * cz, -sx * cy};
+        const double dy[9] = {-sy * cz, -sy * sz, -cy, sx * cy * cz, sx * cy * sz, -sx * sy,
+                              cx * cy * cz, cx * cy * sz, -cx * sy};
+        const double dz[9] = {-cy * sz, cy * cz, 0, -sx * sy * sz - cx * cz, sx * sy * cz - cx * sz, 0,
+                              -cx * sy * sz + sx * cz, cx * sy * cz + sx * sz, 0};
+        for (int k = 0; k < 9; ++k) {
+            g->R[k] = R[k];
+            g->dR[0][k] = dx[k];
+            g->dR[1][k] = dy[k];
+            g->dR[2][k] = dz[k];
+        }
+        for (int c = 0; c < 3; ++c) g->T[c] = tail[3 + c];
+    } else {
+        // nicp_row.py:124,175
+        const double s = sin(tail[0]), c = cos(tail[0]);
+        g->R[0] = c;
+        g->R[1] = s;
+        g->R[2] = -s;
+        g->R[3] = c;
+        g->dR[0][0] = -s;
+        g->dR[0][1] = c;
+        g->dR[0][2] = -c;
+        g->dR[0][3] = -s;
+        g->T[0] = tail[1];
+        g->T[1] = tail[2];
+    }
+}
+
+// ------------------------------------------------------------------ Deform
+// pre_i = sum_k w_ik ((v_i - v_j) A_j + v_j + b_j), j = nbr[i,k];  dd_i = pre_i R + T
+template <int DIM>
+__global__ __launch_bounds__(NB) void deform_kernel(const double *__restrict__ P, const int32_t *__restrict__ nbr,
+                                                   const double *__restrict__ wt, int K, const double *__restrict__ v,
+                                                   int64_t n, const Globals *__restrict__ g, double *__restrict__ pre_out,
+                                                   double *__restrict__ dd_out) {
+    const int64_t i = (int64_t)blockIdx.x * NB + threadIdx.x;
+    if (i >= n) return;
+    constexpr int S = Lay<DIM>::S;
+    double vi[DIM], pre[DIM];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+        vi[c] = v[i * DIM + c];
+        pre[c] = 0.0;
+    }
+    for (int k = 0; k < K; ++k) {
+        const double w = wt[i * K + k];
+        if (w == 0.0) continue;  // nicp_3d.py:227
+        const int64_t j = nbr[i * K + k];
+        const double *Pj = P + j * S;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            double a = 0.0;
+#pragma unroll
+            for (int r = 0; r < DIM; ++r) a += (vi[r] - v[j * DIM + r]) * Pj[r * DIM + c];
+            pre[c] += w * (a + v[j * DIM + c] + Pj[DIM * DIM + c]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < DIM; ++o) {
+        double a = 0.0;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) a += pre[c] * g->R[c * DIM + o];
+        if (dd_out) dd_out[i * DIM + o] = a + g->T[o];
+        if (pre_out) pre_out[i * DIM + o] = pre[o];
+    }
+}
+
+// ------------------------------------------------------------------ residual
+template <int DIM>
+__device__ __forceinline__ void rigid_terms(const double *A, double *out) {
+    if (DIM == 3) {
+        // nicp_3d.py:248-253
+        out[0] = A[0] * A[3] + A[1] * A[4] + A[2] * A[5];
+        out[1] = A[3] * A[6] + A[4] * A[7] + A[5] * A[8];
+        out[2] = A[6] * A[0] + A[7] * A[1] + A[8] * A[2];
+        out[3] = 1 - A[0] * A[0] - A[1] * A[1] - A[2] * A[2];
+        out[4] = 1 - A[3] * A[3] - A[4] * A[4] - A[5] * A[5];
+        out[5] = 1 - A[6] * A[6] - A[7] * A[7] - A[8] * A[8];
+    } else {
+        // nicp_row.py:142-144
+        out[0] = A[0] * A[2] + A[1] * A[3];
+        out[1] = 1 - A[0] * A[0] - A[1] * A[1];
+        out[2] = 1 - A[2] * A[2] - A[3] * A[3];
+    }
+}
+
+template <int DIM, bool COMPAT>
+__global__ __launch_bounds__(NB) void residual_kernel(const double *__restrict__ P, const double *__restrict__ v,
+                                                     const double *__restrict__ nn, const double *__restrict__ dd,
+                                                     const int32_t *__restrict__ edges, int64_t n, int64_t ne,
+                                                     double c_fit, double c_rigid, double c_smooth,
+                                                     double *__restrict__ r) {
+    constexpr int S = Lay<DIM>::S, NRIG = Lay<DIM>::NRIG;
+    const int64_t t = (int64_t)blockIdx.x * NB + threadIdx.x;
+    double *r_rig = r + n * DIM, *r_sm = r + n * DIM + n * NRIG;
+    if (t < n) {
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) r[t * DIM + c] = c_fit * (nn[t * DIM + c] - dd[t * DIM + c]);
+        double e[NRIG];
+        rigid_terms<DIM>(P + t * S, e);
+        if (DIM == 3 && COMPAT) {
+            // Q5: slot 3i..3i+5 written in ascending i: only the three orthogonality terms of
+            // each vertex survive, except the last vertex which keeps all six
+            for (int m = 0; m < 3; ++m) r_rig[t * 3 + m] = c_rigid * e[m];
+            if (t == n - 1)
+                for (int m = 3; m < 6; ++m) r_rig[t * 3 + m] = c_rigid * e[m];
+            for (int64_t s = 3 * n + 3 + t * 3; s < 3 * n + 3 + t * 3 + 3 && s < 6 * n; ++s) r_rig[s] = 0.0;
+        } else {
+            for (int m = 0; m < NRIG; ++m) r_rig[t * NRIG + m] = c_rigid * e[m];
+        }
+    } else if (t < n + ne) {
+        const int64_t ed = t - n;
+        const int64_t p1 = edges[ed * 2], p2 = edges[ed * 2 + 1];
+        const double *P1 = P + p1 * S, *P2 = P + p2 * S;
+        // nicp_3d.py:261-262
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < DIM; ++rr) {
+                const double d = v[p2 * DIM + rr] - v[p1 * DIM + rr];
+                a1 += d * P1[rr * DIM + c];
+                a2 += -d * P2[rr * DIM + c];
+            }
+            const double x1 = v[p1 * DIM + c] + P1[DIM * DIM + c], x2 = v[p2 * DIM + c] + P2[DIM * DIM + c];
+            r_sm[ed * 2 * DIM + c] = c_smooth * (a1 + x1 - x2);
+            r_sm[ed * 2 * DIM + DIM + c] = c_smooth * (a2 + x2 - x1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ y = J p
+template <int DIM, bool COMPAT>
+__global__ __launch_bounds__(NB) void jp_kernel(const double *__restrict__ P, const double *__restrict__ p,
+                                               const int32_t *__restrict__ nbr, const double *__restrict__ wt, int K,
+                                               const double *__restrict__ v, const double *__restrict__ rs,
+                                               const int32_t *__restrict__ edges, int64_t n, int64_t ne,
+                                               const Globals *__restrict__ g, double c_fit, double c_rigid,
+                                               double c_smooth, double *__restrict__ y) {
+    constexpr int S = Lay<DIM>::S, NRIG = Lay<DIM>::NRIG, NANG = Lay<DIM>::NANG;
+    const int64_t t = (int64_t)blockIdx.x * NB + threadIdx.x;
+    double *y_rig = y + n * DIM, *y_sm = y + n * DIM + n * NRIG;
+    const double *ptail = p + n * S;
+    if (t < n) {
+        // fit rows: nicp_3d.py:286-306
+        double vi[DIM], acc[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            vi[c] = v[t * DIM + c];
+            acc[c] = 0.0;
+        }
+        for (int k = 0; k < K; ++k) {
+            const double w = wt[t * K + k];
+            if (w == 0.0) continue;
+            const int64_t j = nbr[t * K + k];
+            const double *pj = p + j * S;
+            const double wb = (DIM == 2 && COMPAT) ? 1.0 : w;  // Q7
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                double a = 0.0;
+#pragma unroll
+                for (int r = 0; r < DIM; ++r) a += (vi[r] - v[j * DIM + r]) * pj[r * DIM + c];
+                acc[c] += w * a + wb * pj[DIM * DIM + c];
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < DIM; ++o) {
+            double a = ptail[NANG + o];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) a += acc[c] * g->R[c * DIM + o];
+            for (int an = 0; an < NANG; ++an) {
+                double b = 0.0;
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) b += rs[t * DIM + c] * g->dR[an][c * DIM + o];
+                a += ptail[an] * b;
+            }
+            y[t * DIM + o] = -c_fit * a;
+        }
+        // rigid rows: nicp_3d.py:309-314 / nicp_row.py:193-204
+        const double *A = P + t * S, *pa = p + t * S;
+        if (DIM == 3) {
+            double d01 = 0, d10 = 0, d12 = 0, d21 = 0, d20 = 0, d02 = 0, d00 = 0, d11 = 0, d22 = 0;
+            for (int c = 0; c < 3; ++c) {
+                d10 += A[3 + c] * pa[c];       // a1 . pa0
+                d01 += A[c] * pa[3 + c];       // a0 . pa1
+                d21 += A[6 + c] * pa[3 + c];   // a2 . pa1
+                d12 += A[3 + c] * pa[6 + c];   // a1 . pa2
+                d20 += A[6 + c] * pa[c];       // a2 . pa0
+                d02 += A[c] * pa[6 + c];       // a0 . pa2
+                d00 += A[c] * pa[c];
+                d11 += A[3 + c] * pa[3 + c];
+                d22 += A[6 + c] * pa[6 + c];
+            }
+            y_rig[t * 6 + 0] = c_rigid * (d10 + d01);
+            y_rig[t * 6 + 1] = c_rigid * (d21 + d12);
+            y_rig[t * 6 + 2] = c_rigid * (d20 + d02);
+            y_rig[t * 6 + 3] = c_rigid * (-2 * d00);
+            y_rig[t * 6 + 4] = c_rigid * (-2 * d11);
+            y_rig[t * 6 + 5] = c_rigid * (-2 * d22);
+        } else {
+            double d10 = 0, d01 = 0, d00 = 0, d11 = 0;
+            for (int c = 0; c < 2; ++c) {
+                d10 += A[2 + c] * pa[c];
+                d01 += A[c] * pa[2 + c];
+                d00 += A[c] * pa[c];
+                d11 += A[2 + c] * pa[2 + c];
+            }
+            y_rig[t * 3 + 0] = c_rigid * (d10 + d01);
+            y_rig[t * 3 + 1] = c_rigid * (-2 * d00);
+            y_rig[t * 3 + 2] = c_rigid * (-2 * d11);
+        }
+    } else if (t < n + ne) {
+        // smooth rows: nicp_3d.py:316-333
+        const int64_t ed = t - n;
+        const int64_t p1 = edges[ed * 2], p2 = edges[ed * 2 + 1];
+        const double *q1 = p + p1 * S, *q2 = p + p2 * S;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int r = 0; r < DIM; ++r) {
+                const double d = v[p2 * DIM + r] - v[p1 * DIM + r];
+                a1 += d * q1[r * DIM + c];
+                a2 += d * q2[r * DIM + c];
+            }
+            const double b1 = q1[DIM * DIM + c], b2 = q2[DIM * DIM + c];
+            y_sm[ed * 2 * DIM + c] = c_smooth * (a1 + b1 - b2);
+            y_sm[ed * 2 * DIM + DIM + c] = c_smooth * (-a2 + b2 - b1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ out = J^T u (+ lam * d2 .* p)
+// SQUARE = true computes the column sums of squares of J (diag of J^T J) instead.
+template <int DIM, bool COMPAT, bool SQUARE>
+__global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, const double *__restrict__ u,
+                                                const int32_t *__restrict__ nbr, const double *__restrict__ wt, int K,
+                                                const double *__restrict__ v, const double *__restrict__ rs,
+                                                const int32_t *__restrict__ edges, const int32_t *__restrict__ rev_ptr,
+                                                const int32_t *__restrict__ rev_ent, const int32_t *__restrict__ inc_ptr,
+                                                const int32_t *__restrict__ inc_ent, int64_t n, int64_t ne,
+                                                const Globals *__restrict__ g, double c_fit, double c_rigid,
+                                                double c_smooth, const double *__restrict__ lam_d2,
+                                                const double *__restrict__ p_in, double lam, double *__restrict__ out,
+                                                double *__restrict__ partial) {
+    constexpr int S = Lay<DIM>::S, NRIG = Lay<DIM>::NRIG, NANG = Lay<DIM>::NANG, NG = Lay<DIM>::NG;
+    const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
+    const double *u_rig = u + n * DIM, *u_sm = u + n * DIM + n * NRIG;
+    double gacc[kSumSlots];
+#pragma unroll
+    for (int k = 0; k < kSumSlots; ++k) gacc[k] = 0.0;
+    if (j < n) {
+        double gA[DIM][DIM], gb[DIM], vj[DIM];
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) {
+            vj[r] = v[j * DIM + r];
+            gb[r] = 0.0;
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) gA[r][c] = 0.0;
+        }
+        // fit rows that reference vertex j
+        for (int32_t e = rev_ptr[j]; e < rev_ptr[j + 1]; ++e) {
+            const int32_t ent = rev_ent[e];
+            const int64_t i = ent / K;
+            const double w = wt[ent];
+            if (w == 0.0) continue;
+            const double wb = (DIM == 2 && COMPAT) ? 1.0 : w;
+            double yv[DIM];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                double a = 0.0;
+#pragma unroll
+                for (int o = 0; o < DIM; ++o) {
+                    const double Rco = g->R[c * DIM + o];
+                    a += SQUARE ? Rco * Rco : Rco * u[i * DIM + o];
+                }
+                yv[c] = a;
+            }
+#pragma unroll
+            for (int r = 0; r < DIM; ++r) {
+                const double d = v[i * DIM + r] - vj[r];
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) gA[r][c] += SQUARE ? (c_fit * w * d) * (c_fit * w * d) * yv[c] : -c_fit * w * d * yv[c];
+            }
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) gb[c] += SQUARE ? (c_fit * wb) * (c_fit * wb) * yv[c] : -c_fit * wb * yv[c];
+        }
+        // rigid rows of vertex j
+        const double *A = P + j * S;
+        if (DIM == 3) {
+            const double *ur = u_rig + j * 6;
+            for (int c = 0; c < 3; ++c) {
+                const double a0 = A[c], a1 = A[3 + c], a2 = A[6 + c];
+                if (SQUARE) {
+                    gA[0][c] += c_rigid * c_rigid * (a1 * a1 + a2 * a2 + 4 * a0 * a0);
+                    gA[1][c] += c_rigid * c_rigid * (a0 * a0 + a2 * a2 + 4 * a1 * a1);
+                    gA[2][c] += c_rigid * c_rigid * (a1 * a1 + a0 * a0 + 4 * a2 * a2);
+                } else {
+                    gA[0][c] += c_rigid * (ur[0] * a1 + ur[2] * a2 - 2 * ur[3] * a0);
+                    gA[1][c] += c_rigid * (ur[0] * a0 + ur[1] * a2 - 2 * ur[4] * a1);
+                    gA[2][c] += c_rigid * (ur[1] * a1 + ur[2] * a0 - 2 * ur[5] * a2);
+                }
+            }
+        } else {
+            const double *ur = u_rig + j * 3;
+            for (int c = 0; c < 2; ++c) {
+                const double a0 = A[c], a1 = A[2 + c];
+                if (SQUARE) {
+                    gA[0][c] += c_rigid * c_rigid * (a1 * a1 + 4 * a0 * a0);
+                    gA[1][c] += c_rigid * c_rigid * (a0 * a0 + 4 * a1 * a1);
+                } else {
+                    gA[0][c] += c_rigid * (ur[0] * a1 - 2 * ur[1] * a0);
+                    gA[1][c] += c_rigid * (ur[0] * a0 - 2 * ur[2] * a1);
+                }
+            }
+        }
+        // smooth rows of the edges incident to vertex j
+        for (int32_t e = inc_ptr[j]; e < inc_ptr[j + 1]; ++e) {
+            const int32_t ent = inc_ent[e];
+            const int64_t ed = ent >> 1;
+            const int end = ent & 1;
+            const int64_t p1 = edges[ed * 2], p2 = edges[ed * 2 + 1];
+            const double *us = u_sm + ed * 2 * DIM;
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                const double u0 = SQUARE ? 1.0 : us[c], u1 = SQUARE ? 1.0 : us[DIM + c];
+#pragma unroll
+                for (int r = 0; r < DIM; ++r) {
+                    const double d = v[p2 * DIM + r] - v[p1 * DIM + r];
+                    if (SQUARE) gA[r][c] += c_smooth * c_smooth * d * d;
+                    else gA[r][c] += end == 0 ? c_smooth * d * u0 : -c_smooth * d * u1;
+                }
+                if (SQUARE) gb[c] += 2 * c_smooth * c_smooth;
+                else gb[c] += end == 0 ? c_smooth * (u0 - u1) : c_smooth * (u1 - u0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < DIM; ++r)
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                const int64_t o = j * S + r * DIM + c;
+                out[o] = gA[r][c] + (lam_d2 ? lam * lam_d2[o] * p_in[o] : 0.0);
+            }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            const int64_t o = j * S + DIM * DIM + c;
+            out[o] = gb[c] + (lam_d2 ? lam * lam_d2[o] * p_in[o] : 0.0);
+        }
+        // global columns: vertex j as fit row j
+        for (int an = 0; an < NANG; ++an) {
+            double a = 0.0;
+#pragma unroll
+            for (int o = 0; o < DIM; ++o) {
+                double b = 0.0;
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) b += rs[j * DIM + c] * g->dR[an][c * DIM + o];
+                a += SQUARE ? (c_fit * b) * (c_fit * b) : -c_fit * b * u[j * DIM + o];
+            }
+            gacc[an] = a;
+        }
+#pragma unroll
+        for (int o = 0; o < DIM; ++o) gacc[NANG + o] = SQUARE ? c_fit * c_fit : -c_fit * u[j * DIM + o];
+    }
+    // block partial of the NG global entries (reduced by tail_kernel)
+    __shared__ double red[NB / 64][NG];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const double s = wave_sum(gacc[k]);
+        if ((tid & 63) == 0) red[tid >> 6][k] = s;
+    }
+    __syncthreads();
+    if (tid < NG) {
+        double s = red[0][tid];
+        for (int w = 1; w < NB / 64; ++w) s += red[w][tid];
+        partial[(int64_t)blockIdx.x * kSumSlots + tid] = s;
+    }
+}
+
+// tail of J^T u: sum the per-block partials of the NG global entries
+__global__ void tail_kernel(const double *__restrict__ partial, int nb, int ng, const double *__restrict__ lam_d2,
+                            const double *__restrict__ p_in, double lam, double *__restrict__ out_tail) {
+    __shared__ double red[NB];
+    const int tid = threadIdx.x;
+    for (int k = 0; k < ng; ++k) {
+        double s = 0.0;
+        for (int b = tid; b < nb; b += NB) s += partial[(int64_t)b * kSumSlots + k];
+        red[tid] = s;
+        __syncthreads();
+        for (int o = NB / 2; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) out_tail[k] = red[0] + (lam_d2 ? lam * lam_d2[k] * p_in[k] : 0.0);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ vector kernels
+// device scalars used by the CG / LM loops
+struct Scal {
+    double rz, rz_new, pAp, rr, rr0, alpha, beta, tmp[8];
+    int32_t stop, iters;
+};
+
+__device__ __forceinline__ void block_sum_to(double vloc, double *partial) {
+    __shared__ double red[NB / 64];
+    const int tid = threadIdx.x;
+    const double s = wave_sum(vloc);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        double t = red[0];
+        for (int w = 1; w < NB / 64; ++w) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+// partial[b] = sum over the block's grid-stride elements of a[i]*b[i]*(w ? w[i] : 1)
+__global__ __launch_bounds__(NB) void dot_kernel(const double *__restrict__ a, const double *__restrict__ b,
+                                                 const double *__restrict__ w, int64_t len, double *__restrict__ partial) {
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * NB + threadIdx.x; i < len; i += (int64_t)gridDim.x * NB)
+        s += a[i] * b[i] * (w ? w[i] : 1.0);
+    block_sum_to(s, partial);
+}
+
+__global__ __launch_bounds__(NB) void final_sum_kernel(const double *__restrict__ partial, int nb, double *__restrict__ out) {
+    __shared__ double red[NB];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int b = tid; b < nb; b += NB) s += partial[b];
+    red[tid] = s;
+    __syncthreads();
+    for (int o = NB / 2; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) *out = red[0];
+}
+
+// CG bookkeeping on the device (no host round trip inside the iteration)
+__global__ void cg_alpha_kernel(Scal *s) {
+    if (s->stop) return;
+    s->alpha = s->pAp > 0 ? s->rz / s->pAp : 0.0;
+    if (!(s->pAp > 0)) s->stop = 2;  // breakdown (non-positive curvature / NaN)
+}
+__global__ void cg_beta_kernel(Scal *s, double tol2) {
+    if (s->stop) return;
+    s->beta = s->rz_new / s->rz;
+    s->rz = s->rz_new;
+    s->iters += 1;
+    if (!(s->rr > tol2 * s->rr0)) s->stop = 1;
+}
+// x += alpha p; r -= alpha Ap; z = r / m; partials of r.z and r.r
+__global__ __launch_bounds__(NB) void cg_update_kernel(const Scal *__restrict__ s, double *__restrict__ x,
+                                                       double *__restrict__ r, double *__restrict__ z,
+                                                       const double *__restrict__ p, const double *__restrict__ Ap,
+                                                       const double *__restrict__ minv, int64_t len,
+                                                       double *__restrict__ part_rz, double *__restrict__ part_rr) {
+    double a = 0.0, b = 0.0;
+    if (!s->stop) {
+        const double alpha = s->alpha;
+        for (int64_t i = (int64_t)blockIdx.x * NB + threadIdx.x; i < len; i += (int64_t)gridDim.x * NB) {
+            x[i] += alpha * p[i];
+            const double ri = r[i] - alpha * Ap[i];
+            r[i] = ri;
+            const double zi = ri * minv[i];
+            z[i] = zi;
+            a += ri * zi;
+            b += ri * ri;
+        }
+    }
+    block_sum_to(a, part_rz);
+    __syncthreads();
+    block_sum_to(b, part_rr);
+}
+__global__ __launch_bounds__(NB) void cg_dir_kernel(const Scal *__restrict__ s, double *__restrict__ p,
+                                                    const double *__restrict__ z, int64_t len) {
+    if (s->stop) return;
+    const double beta = s->beta;
+    for (int64_t i = (int64_t)blockIdx.x * NB + threadIdx.x; i < len; i += (int64_t)gridDim.x * NB)
+        p[i] = z[i] + beta * p[i];
+}
+// generic elementwise helpers
+__global__ __launch_bounds__(NB) void axpby_kernel(double a, const double *__restrict__ x, double b,
+                                                   const double *__restrict__ y, double *__restrict__ out, int64_t len) {
+    for (int64_t i = (int64_t)blockIdx.x * NB + threadIdx.x; i < len; i += (int64_t)gridDim.x * NB)
+        out[i] = a * x[i] + (y ? b * y[i] : 0.0);
+}
+// MINPACK-style scaling: d2 = max(d2_prev, colnorm2) (zero columns -> 1); minv = 1/(colnorm2 + lam d2)
+__global__ __launch_bounds__(NB) void scaling_kernel(const double *__restrict__ col2, double *__restrict__ d2,
+                                                     double *__restrict__ minv, double lam, int first, int64_t len) {
+    for (int64_t i = (int64_t)blockIdx.x * NB + threadIdx.x; i < len; i += (int64_t)gridDim.x * NB) {
+        double c = col2[i];
+        double d = first ? (c > 0 ? c : 1.0) : (d2[i] > c ? d2[i] : c);
+        d2[i] = d;
+        minv[i] = 1.0 / (c + lam * d);
+    }
+}
+
+static inline int grid_for(int64_t len, int cap = 1024) {
+    int64_t nb = (len + NB - 1) / NB;
+    return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
+}
+
+// ------------------------------------------------------------------ host-side driver pieces
+struct Dims {
+    int dim, S, NG, NRIG;
+    int64_t n, e, np, nr;  // np = parameters, nr = residual rows
+};
+static Dims dims_of(const nicp_graph *g) {
+    Dims d;
+    d.dim = g->dim;
+    d.S = g->dim * g->dim + g->dim;
+    d.NG = g->dim == 3 ? 6 : 3;
+    d.NRIG = g->dim == 3 ? 6 : 3;
+    d.n = g->n;
+    d.e = g->e;
+    d.np = g->n * d.S + d.NG;
+    d.nr = g->n * g->dim + g->n * d.NRIG + 2 * g->dim * g->e;
+    return d;
+}
+
+struct Work {
+    Globals *glob;
+    Scal *scal;
+    double *partial;                       // kMaxPartials * kSumSlots
+    double *pre, *dd;                      // [n,dim]
+    double *r, *r_trial, *y;               // nr
+    double *grad, *col2, *d2, *minv;       // np
+    double *delta, *rcg, *z, *pcg, *Ap;    // np
+    double *x_trial;                       // np
+};
+
+static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
+    const Dims d = dims_of(g);
+    const size_t small = 512;  // Globals + Scal, in doubles (generous)
+    const size_t need = small + (size_t)kMaxPartials * kSumSlots + 2 * (size_t)d.n * d.dim + 3 * (size_t)d.nr + 10 * (size_t)d.np + 64;
+    if (g->ws_doubles < need) {
+        if (g->ws) {
+            ICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            ICP_HIP_CHECK(hipFree(g->ws));
+            g->ws = nullptr;
+        }
+        if (hipMalloc((void **)&g->ws, need * sizeof(double)) != hipSuccess) {
+            set_error("nicp workspace: hipMalloc(%zu) failed", need * sizeof(double));
+            return ICP_ERR_NOMEM;
+        }
+        g->ws_doubles = need;
+    }
+    double *p = g->ws;
+    w.glob = (Globals *)p;
+    w.scal = (Scal *)(p + 256);
+    p += small;
+    w.partial = p; p += (size_t)kMaxPartials * kSumSlots;
+    w.pre = p; p += (size_t)d.n * d.dim;
+    w.dd = p; p += (size_t)d.n * d.dim;
+    w.r = p; p += d.nr;
+    w.r_trial = p; p += d.nr;
+    w.y = p; p += d.nr;
+    double **np_bufs[] = {&w.grad, &w.col2, &w.d2, &w.minv, &w.delta, &w.rcg, &w.z, &w.pcg, &w.Ap, &w.x_trial};
+    for (double **b : np_bufs) {
+        *b = p;
+        p += d.np;
+    }
+    return ICP_OK;
+}
+
+#define NICP_DISPATCH(DIMV, COMPATV, CALL)           \
+    do {                                             \
+        if ((DIMV) == 3) {                           \
+            if (COMPATV) { constexpr int D = 3; constexpr bool C = true; CALL; }   \
+            else { constexpr int D = 3; constexpr bool C = false; CALL; }          \
+        } else {                                     \
+            if (COMPATV) { constexpr int D = 2; constexpr bool C = true; CALL; }   \
+            else { constexpr int D = 2; constexpr bool C = false; CALL; }          \
+        }                                            \
+    } while (0)
+
+// linearisation state at P: globals, pre/dd
+static int linearise(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, const double *v) {
+    hipStream_t st = ctx->stream;
+    if (g->dim == 3) {
+        hipLaunchKernelGGL(globals_kernel<3>, dim3(1), dim3(1), 0, st, P, g->n, w.glob);
+        hipLaunchKernelGGL(deform_kernel<3>, dim3(grid_for(g->n, 1 << 30)), dim3(NB), 0, st, P, g->nbr, g->wt, g->k, v, g->n, w.glob, w.pre, w.dd);
+    } else {
+        hipLaunchKernelGGL(globals_kernel<2>, dim3(1), dim3(1), 0, st, P, g->n, w.glob);
+        hipLaunchKernelGGL(deform_kernel<2>, dim3(grid_for(g->n, 1 << 30)), dim3(NB), 0, st, P, g->nbr, g->wt, g->k, v, g->n, w.glob, w.pre, w.dd);
+    }
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+static int residual_at(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, const double *v, const double *nn,
+                       const double *c, bool compat, double *r_out) {
+    if (int rc = linearise(ctx, g, w, P, v)) return rc;
+    const int nbk = grid_for(g->n + g->e, 1 << 30);
+    NICP_DISPATCH(g->dim, compat,
+                  hipLaunchKernelGGL((residual_kernel<D, C>), dim3(nbk), dim3(NB), 0, ctx->stream, P, v, nn, w.dd, g->edges,
+                                     g->n, g->e, c[0], c[1], c[2], r_out));
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+// y = J p at the linearisation held in w (call linearise first)
+static int apply_J(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, const double *v, const double *c, bool compat,
+                   const double *p, double *y) {
+    const int nbk = grid_for(g->n + g->e, 1 << 30);
+    const double *rs = compat ? w.dd : w.pre;  // Q6
+    NICP_DISPATCH(g->dim, compat,
+                  hipLaunchKernelGGL((jp_kernel<D, C>), dim3(nbk), dim3(NB), 0, ctx->stream, P, p, g->nbr, g->wt, g->k, v, rs,
+                                     g->edges, g->n, g->e, w.glob, c[0], c[1], c[2], y));
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+// out = J^T u (+ lam d2 .* p_in); square: out = column sums of squares of J
+static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, const double *v, const double *c, bool compat,
+                    const double *u, const double *lam_d2, const double *p_in, double lam, double *out, bool square) {
+    const Dims d = dims_of(g);
+    const int nbk = grid_for(g->n, 1 << 30);
+    const double *rs = compat ? w.dd : w.pre;
+    if (nbk > kMaxPartials) {
+        set_error("nicp: mesh too large for the partial buffer (%lld vertices)", (long long)g->n);
+        return ICP_ERR_UNSUPPORTED;
+    }
+    if (square) {
+        NICP_DISPATCH(g->dim, compat,
+                      hipLaunchKernelGGL((jtu_kernel<D, C, true>), dim3(nbk), dim3(NB), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,
+                                         rs, g->edges, g->rev_ptr, g->rev_ent, g->inc_ptr, g->inc_ent, g->n, g->e, w.glob,
+                                         c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial));
+    } else {
+        NICP_DISPATCH(g->dim, compat,
+                      hipLaunchKernelGGL((jtu_kernel<D, C, false>), dim3(nbk), dim3(NB), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,
+                                         rs, g->edges, g->rev_ptr, g->rev_ent, g->inc_ptr, g->inc_ent, g->n, g->e, w.glob,
+                                         c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial));
+    }
+    ICP_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(tail_kernel, dim3(1), dim3(NB), 0, ctx->stream, w.partial, nbk, d.NG,
+                       lam_d2 ? lam_d2 + d.n * d.S : nullptr, p_in ? p_in + d.n * d.S : nullptr, lam, out + d.n * d.S);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+static int dot_to(icp_ctx *ctx, Work &w, const double *a, const double *b, const double *wv, int64_t len, double *out_dev) {
+    const int nbk = grid_for(len);
+    hipLaunchKernelGGL(dot_kernel, dim3(nbk), dim3(NB), 0, ctx->stream, a, b, wv, len, w.partial);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, ctx->stream, (const double *)w.partial, nbk, out_dev);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+static int read_scal(icp_ctx *ctx, const Scal *dev, Scal &host) {
+    ICP_HIP_CHECK(hipMemcpyAsync(&host, dev, sizeof(Scal), hipMemcpyDeviceToHost, ctx->stream));
+    ICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return ICP_OK;
+}
+
+}  // namespace icp
+
+using namespace icp;
+
+// ===================================================================== C-ABI
+extern "C" int nicp_knn(icp_ctx *ctx, const double *v, int64_t n, int dim, const double *q, int64_t nq, int k,
+                        int32_t *idx_out, double *dist_out) {
+    ICP_REQUIRE(ctx && v && q && idx_out && dist_out, "null pointer");
+    ICP_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
+    ICP_REQUIRE(n > 0 && nq >= 0 && (k == 6 || k == 8), "k must be 6 or 8 (use 8 and truncate for other k <= 8)");
+    ICP_REQUIRE(n >= k, "fewer points than k (nicp3d.cpp:130-135 pops an empty heap; refused here)");
+    if (nq == 0) return ICP_OK;
+    ICP_HIP_CHECK(hipSetDevice(ctx->device));
+    const unsigned nb = (unsigned)((nq + NB - 1) / NB);
+    hipStream_t st = ctx->stream;
+    if (dim == 3 && k == 6) hipLaunchKernelGGL((knn_rows_kernel<3, 6>), dim3(nb), dim3(NB), 0, st, v, n, q, nq, idx_out, dist_out);
+    else if (dim == 3) hipLaunchKernelGGL((knn_rows_kernel<3, 8>), dim3(nb), dim3(NB), 0, st, v, n, q, nq, idx_out, dist_out);
+    else if (k == 6) hipLaunchKernelGGL((knn_rows_kernel<2, 6>), dim3(nb), dim3(NB), 0, st, v, n, q, nq, idx_out, dist_out);
+    else hipLaunchKernelGGL((knn_rows_kernel<2, 8>), dim3(nb), dim3(NB), 0, st, v, n, q, nq, idx_out, dist_out);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+extern "C" int nicp_knn_weights(icp_ctx *ctx, const double *v, int64_t n, int dim, int num_nn, int32_t *nbr_out,
+                                double *wt_out) {
+    ICP_REQUIRE(ctx && v && nbr_out && wt_out, "null pointer");
+    ICP_REQUIRE(num_nn == 4, "num_nn must be 4 (nicp_3d.py:17, nicp3d.cpp:25)");
+    ICP_REQUIRE(n >= num_nn + 2, "need at least num_nn+2 vertices");
+    ICP_HIP_CHECK(hipSetDevice(ctx->device));
+    const int K = num_nn + 2;
+    if (int rc = ensure(ctx, ctx->work_a, (size_t)n * K * sizeof(int32_t))) return rc;
+    if (int rc = ensure(ctx, ctx->work_b, (size_t)n * K * sizeof(double))) return rc;
+    int32_t *kidx = (int32_t *)ctx->work_a.ptr;
+    double *kdist = (double *)ctx->work_b.ptr;
+    if (int rc = nicp_knn(ctx, v, n, dim, v, n, K, kidx, kdist)) return rc;
+    hipLaunchKernelGGL(knn_weights_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, kidx, kdist, n,
+                       nbr_out, wt_out);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+extern "C" int nicp_graph_destroy(icp_ctx *ctx, nicp_graph *g) {
+    if (!g) return ICP_OK;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    void *ptrs[] = {g->nbr, g->wt, g->edges, g->rev_ptr, g->rev_ent, g->inc_ptr, g->inc_ent, g->ws};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete g;
+    return ICP_OK;
+}
+
+extern "C" int nicp_graph_create(icp_ctx *ctx, const int32_t *nbr_dev, const double *wt_dev, int64_t n, int num_nn,
+                                 const int32_t *edges_dev, int64_t e, int dim, nicp_graph **out) {
+    ICP_REQUIRE(ctx && nbr_dev && wt_dev && out, "null pointer");
+    ICP_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
+    ICP_REQUIRE(n > 0 && num_nn > 0 && num_nn <= 8 && e >= 0 && (e == 0 || edges_dev), "bad sizes");
+    ICP_REQUIRE(n * num_nn < 0x7fffffff && 2 * e < 0x7fffffff, "mesh too large for 32-bit adjacency entries");
+    ICP_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<int32_t> nbr((size_t)n * num_nn), edges((size_t)e * 2);
+    ICP_HIP_CHECK(hipMemcpyAsync(nbr.data(), nbr_dev, nbr.size() * 4, hipMemcpyDeviceToHost, st));
+    if (e) ICP_HIP_CHECK(hipMemcpyAsync(edges.data(), edges_dev, edges.size() * 4, hipMemcpyDeviceToHost, st));
+    ICP_HIP_CHECK(hipStreamSynchronize(st));
+    for (int32_t x : nbr) ICP_REQUIRE(x >= 0 && x < n, "neighbour index out of range");
+    for (int32_t x : edges) ICP_REQUIRE(x >= 0 && x < n, "edge vertex out of range");
+    // reverse adjacency by counting sort (entries ascending within each row -> deterministic sums)
+    std::vector<int32_t> rev_ptr(n + 1, 0), rev_ent(nbr.size()), inc_ptr(n + 1, 0), inc_ent(edges.size());
+    for (int32_t x : nbr) rev_ptr[x + 1]++;
+    for (int64_t i = 0; i < n; ++i) rev_ptr[i + 1] += rev_ptr[i];
+    {
+        std::vector<int32_t> cur(rev_ptr.begin(), rev_ptr.end() - 1);
+        for (size_t t = 0; t < nbr.size(); ++t) rev_ent[cur[nbr[t]]++] = (int32_t)t;
+    }
+    for (int32_t x : edges) inc_ptr[x + 1]++;
+    for (int64_t i = 0; i < n; ++i) inc_ptr[i + 1] += inc_ptr[i];
+    {
+        std::vector<int32_t> cur(inc_ptr.begin(), inc_ptr.end() - 1);
+        for (size_t t = 0; t < edges.size(); ++t) inc_ent[cur[edges[t]]++] = (int32_t)t;  // t = e*2+end
+    }
+    nicp_graph *g = new nicp_graph();
+    g->n = n;
+    g->e = e;
+    g->dim = dim;
+    g->k = num_nn;
+    auto up = [&](void **dst, const void *src, size_t bytes) -> int {
+        if (hipMalloc(dst, bytes ? bytes : 8) != hipSuccess) return ICP_ERR_NOMEM;
+        if (bytes && hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return ICP_ERR_HIP;
+        return ICP_OK;
+    };
+    int rc = ICP_OK;
+    if (hipMalloc((void **)&g->nbr, nbr.size() * 4) != hipSuccess || hipMalloc((void **)&g->wt, nbr.size() * 8) != hipSuccess) rc = ICP_ERR_NOMEM;
+    if (!rc && hipMemcpyAsync(g->nbr, nbr_dev, nbr.size() * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = ICP_ERR_HIP;
+    if (!rc && hipMemcpyAsync(g->wt, wt_dev, nbr.size() * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = ICP_ERR_HIP;
+    if (!rc) rc = up((void **)&g->edges, edges.data(), edges.size() * 4);
+    if (!rc) rc = up((void **)&g->rev_ptr, rev_ptr.data(), rev_ptr.size() * 4);
+    if (!rc) rc = up((void **)&g->rev_ent, rev_ent.data(), rev_ent.size() * 4);
+    if (!rc) rc = up((void **)&g->inc_ptr, inc_ptr.data(), inc_ptr.size() * 4);
+    if (!rc) rc = up((void **)&g->inc_ent, inc_ent.data(), inc_ent.size() * 4);
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = ICP_ERR_HIP;
+    if (rc) {
+        set_error("nicp_graph_create: device allocation / upload failed");
+        nicp_graph_destroy(ctx, g);
+        return rc;
+    }
+    *out = g;
+    return ICP_OK;
+}
+
+#define NICP_ARGS(ctx, g)                                     \
+    ICP_REQUIRE(ctx != nullptr && g != nullptr, "null handle"); \
+    ICP_HIP_CHECK(hipSetDevice(ctx->device));                 \
+    Work w;                                                   \
+    if (int rc_ = get_work(ctx, g, w)) return rc_
+
+extern "C" int nicp_deform(icp_ctx *ctx, nicp_graph *g, const double *P, const double *v, double *out) {
+    NICP_ARGS(ctx, g);
+    ICP_REQUIRE(P && v && out, "null pointer");
+    if (int rc = linearise(ctx, g, w, P, v)) return rc;
+    ICP_HIP_CHECK(hipMemcpyAsync(out, w.dd, (size_t)g->n * g->dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return ICP_OK;
+}
+
+extern "C" int nicp_residual(icp_ctx *ctx, nicp_graph *g, const double *P, const double *v, const double *nn,
+                             const double *c3_host, unsigned flags, double *r_out) {
+    NICP_ARGS(ctx, g);
+    ICP_REQUIRE(P && v && nn && c3_host && r_out, "null pointer");
+    return residual_at(ctx, g, w, P, v, nn, c3_host, flags & 1u, r_out);
+}
+
+extern "C" int nicp_jvp(icp_ctx *ctx, nicp_graph *g, const double *P, const double *v, const double *c3_host,
+                        unsigned flags, const double *p_in, double *y_out) {
+    NICP_ARGS(ctx, g);
+    ICP_REQUIRE(P && v && c3_host && p_in && y_out, "null pointer");
+    if (int rc = linearise(ctx, g, w, P, v)) return rc;
+    return apply_J(ctx, g, w, P, v, c3_host, flags & 1u, p_in, y_out);
+}
+
+extern "C" int nicp_jtvp(icp_ctx *ctx, nicp_graph *g, const double *P, const double *v, const double *c3_host,
+                         unsigned flags, const double *u_in, double *g_out) {
+    NICP_ARGS(ctx, g);
+    ICP_REQUIRE(P && v && c3_host && u_in && g_out, "null pointer");
+    if (int rc = linearise(ctx, g, w, P, v)) return rc;
+    return apply_JT(ctx, g, w, P, v, c3_host, flags & 1u, u_in, nullptr, nullptr, 0.0, g_out, false);
+}
+
+extern "C" int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, const double *nn,
+                          const double *c3_host, unsigned flags, const nicp_solve_opts *opts_in,
+                          nicp_solve_stats *stats_out) {
+    NICP_ARGS(ctx, g);
+    ICP_REQUIRE(P_inout && v && nn && c3_host, "null pointer");
+    const bool compat = flags & 1u;
+    const Dims d = dims_of(g);
+    nicp_solve_opts o = {1.49012e-8, 1.49012e-8, 0.0, 1e-3, 1e-10, 100, 0};
+    if (opts_in) o = *opts_in;
+    if (o.max_cg_iters <= 0) o.max_cg_iters = (int)std::min<int64_t>(20000, 4 * d.np + 100);
+    hipStream_t st = ctx->stream;
+    const double *c = c3_host;
+    Scal hs;
+    nicp_solve_stats stt = {0, 0, 0, 0, 0, 0};
+    const int nbp = grid_for(d.np);
+
+    double *x = P_inout;
+    if (int rc = residual_at(ctx, g, w, x, v, nn, c, compat, w.r)) return rc;
+    if (int rc = dot_to(ctx, w, w.r, w.r, nullptr, d.nr, &w.scal->tmp[0])) return rc;
+    if (int rc = read_scal(ctx, w.scal, hs)) return rc;
+    double f2 = hs.tmp[0];
+    stt.err0 = f2;
+    stt.nfev = 1;
+    double lam = o.lambda0, nu = 2.0;
+    int info = 0;
+    bool first_scaling = true;
+    for (int it = 0; it < o.max_lm_iters && !info; ++it) {
+        stt.lm_iters = it + 1;
+        if (!(f2 == f2) || std::isinf(f2)) {
+            set_error("nicp_solve: residual is not finite");
+            return ICP_ERR_NUMERIC;
+        }
+        // linearise at x (w.r holds r(x) and w.pre/dd/glob are those of x after residual_at)
+        if (int rc = linearise(ctx, g, w, x, v)) return rc;
+        if (int rc = apply_JT(ctx, g, w, x, v, c, compat, w.r, nullptr, nullptr, 0.0, w.grad, false)) return rc;
+        if (int rc = apply_JT(ctx, g, w, x, v, c, compat, w.r, nullptr, nullptr, 0.0, w.col2, true)) return rc;
+        bool accepted = false;
+        bool relinearise = false;
+        while (!accepted && !info) {
+            if (relinearise)  // a rejected trial left the linearisation state at x_trial
+                if (int rc = linearise(ctx, g, w, x, v)) return rc;
+            hipLaunchKernelGGL(scaling_kernel, dim3(nbp), dim3(NB), 0, st, w.col2, w.d2, w.minv, lam, first_scaling ? 1 : 0, d.np);
+            first_scaling = false;
+            // ---- CG on (J^T J + lam D^2) delta = -grad, Jacobi preconditioner
+            ICP_HIP_CHECK(hipMemsetAsync(w.delta, 0, d.np * sizeof(double), st));
+            ICP_HIP_CHECK(hipMemsetAsync(w.pcg, 0, d.np * sizeof(double), st));
+            ICP_HIP_CHECK(hipMemsetAsync(w.Ap, 0, d.np * sizeof(double), st));
+            hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, -1.0, w.grad, 0.0, (const double *)nullptr, w.rcg, d.np);
+            ICP_HIP_CHECK(hipMemsetAsync(w.scal, 0, sizeof(Scal), st));
+            // z = M^-1 r ; p = z ; rz = r.z ; rr0 = r.r
+            hipLaunchKernelGGL(cg_update_kernel, dim3(nbp), dim3(NB), 0, st, (const Scal *)w.scal, w.delta, w.rcg, w.z, w.pcg, w.Ap, w.minv, d.np,
+                               w.partial, w.partial + kMaxPartials);  // alpha = 0: only builds z and the dots
+            hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, st, (const double *)w.partial, nbp, &w.scal->rz);
+            hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, st, (const double *)(w.partial + kMaxPartials), nbp, &w.scal->rr0);
+            hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, 1.0, w.z, 0.0, (const double *)nullptr, w.pcg, d.np);
+            ICP_HIP_CHECK(hipGetLastError());
+            int cg_done = 0;
+            for (int ci = 0; ci < o.max_cg_iters && !cg_done;) {
+                const int chunk = std::min(50, o.max_cg_iters - ci);
+                for (int k = 0; k < chunk; ++k) {
+                    if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.pcg, w.y)) return rc;
+                    if (int rc = apply_JT(ctx, g, w, x, v, c, compat, w.y, w.d2, w.pcg, lam, w.Ap, false)) return rc;
+                    hipLaunchKernelGGL(dot_kernel, dim3(nbp), dim3(NB), 0, st, w.pcg, w.Ap, (const double *)nullptr, d.np, w.partial);
+                    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, st, (const double *)w.partial, nbp, &w.scal->pAp);
+                    hipLaunchKernelGGL(cg_alpha_kernel, dim3(1), dim3(1), 0, st, w.scal);
+                    hipLaunchKernelGGL(cg_update_kernel, dim3(nbp), dim3(NB), 0, st, (const Scal *)w.scal, w.delta, w.rcg, w.z, w.pcg, w.Ap,
+                                       w.minv, d.np, w.partial, w.partial + kMaxPartials);
+                    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, st, (const double *)w.partial, nbp, &w.scal->rz_new);
+                    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, st, (const double *)(w.partial + kMaxPartials), nbp, &w.scal->rr);
+                    hipLaunchKernelGGL(cg_beta_kernel, dim3(1), dim3(1), 0, st, w.scal, o.cg_tol * o.cg_tol);
+                    hipLaunchKernelGGL(cg_dir_kernel, dim3(nbp), dim3(NB), 0, st, (const Scal *)w.scal, w.pcg, w.z, d.np);
+                }
+                ICP_HIP_CHECK(hipGetLastError());
+                ci += chunk;
+                if (int rc = read_scal(ctx, w.scal, hs)) return rc;
+                cg_done = hs.stop;
+            }
+            stt.cg_iters += hs.iters;
+            // ---- trial point and gain ratio
+            hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, 1.0, (const double *)x, 1.0, (const double *)w.delta, w.x_trial, d.np);
+            // predicted reduction of |r|^2 : delta^T (lam D^2 delta - grad)
+            if (int rc = dot_to(ctx, w, w.delta, w.delta, w.d2, d.np, &w.scal->tmp[1])) return rc;   // |D delta|^2
+            if (int rc = dot_to(ctx, w, w.delta, w.grad, nullptr, d.np, &w.scal->tmp[2])) return rc;
+            if (int rc = dot_to(ctx, w, x, x, w.d2, d.np, &w.scal->tmp[3])) return rc;               // |D x|^2
+            if (int rc = dot_to(ctx, w, w.grad, w.grad, nullptr, d.np, &w.scal->tmp[4])) return rc;
+            if (int rc = residual_at(ctx, g, w, w.x_trial, v, nn, c, compat, w.r_trial)) return rc;
+            if (int rc = dot_to(ctx, w, w.r_trial, w.r_trial, nullptr, d.nr, &w.scal->tmp[0])) return rc;
+            if (int rc = read_scal(ctx, w.scal, hs)) return rc;
+            stt.nfev++;
+            const double f2t = hs.tmp[0], dn2 = hs.tmp[1], dg = hs.tmp[2], xn2 = hs.tmp[3], gg = hs.tmp[4];
+            const double pred = lam * dn2 - dg;  // = |r|^2 - |r + J delta|^2 - lam|D delta|^2 ... >= 0 for an exact solve
+            const double actred = f2 - f2t;
+            const double ratio = pred > 0 ? actred / pred : (actred > 0 ? 1.0 : -1.0);
+            if (f2t == f2t && ratio > 1e-4) {
+                // accept (lmder accepts at ratio >= 1e-4)
+                ICP_HIP_CHECK(hipMemcpyAsync(x, w.x_trial, d.np * sizeof(double), hipMemcpyDeviceToDevice, st));
+                std::swap(w.r, w.r_trial);
+                accepted = true;
+                const double t = 2 * ratio - 1;
+                lam *= std::max(1.0 / 3.0, 1 - t * t * t);
+                nu = 2.0;
+                // MINPACK's tests (lmder.f): relative reductions and relative step
+                const bool t_f = std::fabs(actred) <= o.ftol * f2 && pred <= o.ftol * f2 && 0.5 * ratio <= 1;
+                const bool t_x = std::sqrt(dn2) <= o.xtol * std::sqrt(xn2);
+                f2 = f2t;
+                if (t_f) info = 1;
+                if (t_x) info = info == 1 ? 3 : 2;
+            } else {
+                relinearise = true;
+                lam *= nu;
+                nu *= 2.0;
+                if (std::sqrt(dn2) <= o.xtol * std::sqrt(xn2) || lam > 1e30) info = 2;  // step collapsed without progress
+            }
+            if (!info && o.gtol > 0 && std::sqrt(gg) <= o.gtol * std::sqrt(f2)) info = 4;
+        }
+    }
+    if (!info) info = 5;
+    stt.info = info;
+    stt.err = f2;
+    if (stats_out) *stats_out = stt;
+    ICP_HIP_CHECK(hipStreamSynchronize(st));
+    return ICP_OK;
+}

@@ -122,6 +122,74 @@ int icp_shard_apply_err(icp_ctx *ctx, const double *src, const double *tgt, cons
 /* column sums of a [n,dim] array -> out_dev[dim] (for the shifts above) */
 int icp_column_sums(icp_ctx *ctx, const double *a, int64_t n, int dim, double *out_dev);
 
+/* ------------------------------------------------------------ non-rigid ICP */
+
+typedef struct nicp_graph nicp_graph;
+
+/* flags for the nicp_* operators */
+enum {
+    NICP_REFERENCE_COMPAT = 1u /* reproduce the reference's quirks Q5/Q6/Q7; 0 =
+                                  self-consistent residual/Jacobian pair */
+};
+
+/* KNN: nicp_3d.py:53-57 / nicp3d.cpp:100-137.  For every row of q[nq,dim] the k smallest
+ * Euclidean distances (fp64, with sqrt) to the rows of v[n,dim], ascending, ties to the lower
+ * index; k must be 6 or 8.  idx_out[nq,k] int32, dist_out[nq,k]. */
+int nicp_knn(icp_ctx *ctx, const double *v, int64_t n, int dim, const double *q, int64_t nq, int k,
+             int32_t *idx_out, double *dist_out);
+
+/* The weight loop of Initialise: nicp_3d.py:158-164 / nicp_row.py:100-106 /
+ * nicp3d.cpp:196-215.  Sparse form of the reference's dense w[N,N]:
+ * w[nbr_out[j,i], j] = wt_out[j,i], i < num_nn (= 4). */
+int nicp_knn_weights(icp_ctx *ctx, const double *v, int64_t n, int dim, int num_nn, int32_t *nbr_out,
+                     double *wt_out);
+
+/* Mesh connectivity handle: copies nbr/wt/edges[e,2] and builds the reverse adjacency used by
+ * the J^T products (synchronises; once per mesh).  Replaces the dense `weights` member
+ * (nicp3d.cpp:39,199) and the `w`, `edges` arguments of nicp_3d.py:220,239,274,344. */
+int nicp_graph_create(icp_ctx *ctx, const int32_t *nbr_dev, const double *wt_dev, int64_t n, int num_nn,
+                      const int32_t *edges_dev, int64_t e, int dim, nicp_graph **out);
+int nicp_graph_destroy(icp_ctx *ctx, nicp_graph *g);
+
+/* Deform: nicp_3d.py:220-233 / nicp_row.py:112-126 / nicp3d.cpp:277-371.  P has
+ * (dim*dim+dim)*n + (dim==3 ? 6 : 3) entries (PtoAB layout, nicp_3d.py:171-175). */
+int nicp_deform(icp_ctx *ctx, nicp_graph *g, const double *P, const double *v, double *out);
+
+/* MinFunc: nicp_3d.py:239-267 / nicp_row.py:132-160.  c3_host = {c_fit, c_rigid, c_smooth}
+ * (HOST pointer).  r_out has dim*n + (dim==3 ? 6 : 3)*n + 2*dim*e entries. */
+int nicp_residual(icp_ctx *ctx, nicp_graph *g, const double *P, const double *v, const double *nn,
+                  const double *c3_host, unsigned flags, double *r_out);
+
+/* Products with the Jacobian D_MinFunc builds densely (nicp_3d.py:274-338 / nicp_row.py:167-230)
+ * without forming it: y = J p, g = J^T u. */
+int nicp_jvp(icp_ctx *ctx, nicp_graph *g, const double *P, const double *v, const double *c3_host,
+             unsigned flags, const double *p_in, double *y_out);
+int nicp_jtvp(icp_ctx *ctx, nicp_graph *g, const double *P, const double *v, const double *c3_host,
+              unsigned flags, const double *u_in, double *g_out);
+
+/* options / statistics of nicp_solve (plain old data in HOST memory) */
+typedef struct nicp_solve_opts {
+    double ftol, xtol, gtol; /* MINPACK-style relative tolerances; leastsq defaults 1.49012e-8, 1.49012e-8, 0 */
+    double lambda0;          /* initial Levenberg-Marquardt damping (1e-3) */
+    double cg_tol;           /* relative residual of the inner conjugate-gradient solve (1e-10) */
+    int max_lm_iters;        /* outer iterations (100) */
+    int max_cg_iters;        /* per linear solve (0 = automatic) */
+} nicp_solve_opts;
+typedef struct nicp_solve_stats {
+    double err;  /* sum of squared residuals at the returned P (nicp_3d.py:353) */
+    double err0; /* ... at the initial P */
+    int lm_iters, cg_iters, nfev;
+    int info;    /* 1 ftol, 2 xtol, 3 both, 4 gtol, 5 iteration limit */
+} nicp_solve_stats;
+
+/* The optimize.leastsq call of nicp_3d.py:351 / nicp_row.py:246: minimise |MinFunc(P)|^2 from
+ * P_inout with correspondences nn fixed.  Levenberg-Marquardt; each step solves
+ * (J^T J + lambda D^2) delta = -J^T r by Jacobi-preconditioned conjugate gradients on the
+ * matrix-free operators above.  opts_host may be NULL; stats_host may be NULL.  Synchronises. */
+int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, const double *nn,
+               const double *c3_host, unsigned flags, const nicp_solve_opts *opts_host,
+               nicp_solve_stats *stats_host);
+
 #ifdef __cplusplus
 }
 #endif

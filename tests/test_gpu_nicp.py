@@ -1,0 +1,200 @@
+"""GPU parity tests for the NICP path (KNN weights, Deform, residual, Jacobian products,
+LM-CG solve, outer loop) against the golden fixtures / the oracle.  Tolerance for fp64
+values: 1e-6 relative (north_star); KNN indices are exact."""
+import numpy as np
+import pytest
+
+import icp_oracle as orc
+import c_oracle
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+C = (0.1, 1000.0, 100.0)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    assert torch.cuda.is_available()
+    from icp_amd import nicp, nicp_3d
+    return dict(nicp=nicp, nicp_3d=nicp_3d, torch=torch)
+
+
+def sparse_from_dense(w, k=4):
+    n = w.shape[0]
+    nbr = np.zeros((n, k), np.int32)
+    wt = np.zeros((n, k))
+    for j in range(n):
+        nz = np.nonzero(w[:, j])[0]
+        nbr[j] = nz
+        wt[j] = w[nz, j]
+    return nbr, wt
+
+
+@pytest.mark.parametrize("name", ["nicp_init_60", "nicp_init_200"])
+def test_initialise_golden(mods, name):
+    g = golden(name)
+    v = g["v"]
+    P, w = mods["nicp_3d"].Initialise(v, g["tgt"])
+    assert np.array_equal(P, g["P0"])
+    np.testing.assert_allclose(w.toarray(), g["w"], rtol=1e-12, atol=1e-15)
+    assert np.array_equal(w.toarray() != 0, g["w"] != 0)          # same sparsity = same neighbours
+    np.testing.assert_allclose(w.sum(0), 1.0, atol=1e-14)
+    for row, j in enumerate(range(0, v.shape[0], 7)):
+        idx, dist = mods["nicp_3d"].KNN(v, v[j], 6)
+        assert np.array_equal(idx, g["knn_idx"][row])
+        assert np.array_equal(dist, g["knn_dist"][row])            # sqrt is correctly rounded
+    np.testing.assert_allclose(mods["nicp_3d"].Deform(g["P0"], w, v), g["deform_id"], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(mods["nicp_3d"].Deform(g["P_rand"], w, v), g["deform_rand"], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(mods["nicp_3d"].Deform(g["P_rand"], g["w"], v), g["deform_rand"], rtol=RTOL, atol=1e-12)
+    assert np.array_equal(mods["nicp_3d"].RotMatrix(0.3, -0.4, 0.5), g["R"])
+
+
+def test_knn_vs_c_oracle_ties(mods):
+    # lattice with exact distance ties + duplicates: order must be (distance, index)
+    gpts = np.stack(np.meshgrid(np.arange(8.), np.arange(8.), np.arange(4.), indexing="ij"), -1).reshape(-1, 3)
+    v = np.concatenate([gpts, gpts[:40]])
+    idx, dist = mods["nicp"].knn(v, v, 6)
+    oi, od = c_oracle.knn_rows(v, 6)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(dist.cpu().numpy(), od)
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal((5000, 3))
+    idx, dist = mods["nicp"].knn(v, v, 6)
+    oi, od = c_oracle.knn_rows(v, 6)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(dist.cpu().numpy(), od)
+    idx8, dist8 = mods["nicp"].knn(v, v[:100], 8)
+    oi8, od8 = c_oracle.knn_rows(v, 8)
+    assert np.array_equal(idx8.cpu().numpy(), oi8[:100])
+    v2 = rng.standard_normal((700, 2))
+    idx, dist = mods["nicp"].knn(v2, v2, 6)
+    oi, od = c_oracle.knn_rows(v2, 6)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(dist.cpu().numpy(), od)
+
+
+@pytest.mark.parametrize("name", ["nicp_step_24", "nicp_step_60"])
+def test_residual_and_jacobian_golden(mods, name):
+    g = golden(name)
+    n3 = mods["nicp_3d"]
+    v, edges, nn, P = g["v"], g["edges"], g["nn"], g["P_rand"]
+    r = n3.MinFunc(P, g["w"], v, edges, nn)
+    np.testing.assert_allclose(r, g["r"], rtol=RTOL, atol=1e-9)
+    nzr = g["r"][3 * len(v):9 * len(v)] != 0                        # Q5 layout: same slots populated
+    assert np.array_equal(r[3 * len(v):9 * len(v)] != 0, nzr)
+    Jv = mods["nicp"].jvp(P, g["w"], v, edges, C, g["pv"]).cpu().numpy()
+    np.testing.assert_allclose(Jv, g["Jv"], rtol=RTOL, atol=1e-7)
+    JTu = mods["nicp"].jtvp(P, g["w"], v, edges, C, g["pu"]).cpu().numpy()
+    np.testing.assert_allclose(JTu, g["JTu"], rtol=RTOL, atol=1e-7)
+    if "J" in g.files:
+        J = n3.D_MinFunc(P, g["w"], v, edges, nn)
+        np.testing.assert_allclose(J, g["J"], rtol=RTOL, atol=1e-9)
+
+
+def test_corrected_mode_operators(mods):
+    g = golden("nicp_step_24")
+    v, edges, nn, P = g["v"], g["edges"], g["nn"], g["P_rand"]
+    nbr, wt = sparse_from_dense(g["w"])
+    r = mods["nicp"].residual(P, g["w"], v, edges, nn, C, compat=False).cpu().numpy()
+    np.testing.assert_allclose(r, orc.min_func(P, nbr, wt, v, edges, nn, compat=False), rtol=RTOL, atol=1e-9)
+    Jo = orc.d_min_func(P, nbr, wt, v, edges, nn, compat=False)
+    Jv = mods["nicp"].jvp(P, g["w"], v, edges, C, g["pv"], compat=False).cpu().numpy()
+    np.testing.assert_allclose(Jv, Jo @ g["pv"], rtol=RTOL, atol=1e-7)
+    JTu = mods["nicp"].jtvp(P, g["w"], v, edges, C, g["pu"], compat=False).cpu().numpy()
+    np.testing.assert_allclose(JTu, Jo.T @ g["pu"], rtol=RTOL, atol=1e-7)
+
+
+def test_row2d_operators(mods):
+    g = golden("nicp_row_20")
+    v, edges, nn, P = g["v"], g["edges"], g["nn"], g["P_rand"]
+    nic = mods["nicp"]
+    w = nic.knn_weights(v)
+    np.testing.assert_allclose(w.toarray(), g["w"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(nic.deform(P, w, v).cpu().numpy(), g["deform_rand"], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(nic.residual(P, w, v, edges, nn, (0.1, 1000, 100)).cpu().numpy(), g["r"], rtol=RTOL, atol=1e-9)
+    J = nic.dense_jacobian(P, w, v, edges, (0.1, 1000, 100)).cpu().numpy()
+    np.testing.assert_allclose(J, g["J"], rtol=RTOL, atol=1e-9)                # incl. Q7
+    rng = np.random.default_rng(1)
+    u = rng.standard_normal(J.shape[0])
+    np.testing.assert_allclose(nic.jtvp(P, w, v, edges, (0.1, 1000, 100), u).cpu().numpy(), g["J"].T @ u, rtol=RTOL, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["nicp_step_24", "nicp_step_60"])
+def test_solve_corrected_vs_leastsq(mods, name):
+    """Self-consistent residual/Jacobian: the minimiser is well defined, so the LM-CG solve
+    must land on scipy.optimize.leastsq's deformed vertices to 1e-6."""
+    from scipy import optimize
+    g = golden(name)
+    v, edges, nn, P0 = g["v"], g["edges"], g["nn"], g["P0"]
+    nbr, wt = sparse_from_dense(g["w"])
+    lsq = optimize.leastsq(lambda p: orc.min_func(p, nbr, wt, v, edges, nn, C, False), P0,
+                           Dfun=lambda p: orc.d_min_func(p, nbr, wt, v, edges, nn, C, False), full_output=1)
+    dd_ref = orc.deform(lsq[0], nbr, wt, v)
+    e_ref = (lsq[2]["fvec"] ** 2).sum()
+    P, st = mods["nicp"].solve(P0, g["w"], v, edges, nn, C, compat=False)
+    dd = mods["nicp"].deform(P, g["w"], v).cpu().numpy()
+    print(name, "corrected: leastsq err", e_ref, "gpu", st)
+    np.testing.assert_allclose(st["err"], e_ref, rtol=1e-6)
+    np.testing.assert_allclose(dd, dd_ref, rtol=RTOL, atol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["nicp_step_24", "nicp_step_60"])
+def test_solve_compat_vs_golden(mods, name):
+    """Reference-as-coded mode: the Jacobian is not the derivative of the residual (Q5/Q6), so
+    MINPACK stops where its trust region collapses (ier=2) -- a path-dependent point no other
+    solver can hit exactly (DESIGN.md 'NICP solve parity').  Pinned here: the GPU solve reaches
+    an energy no worse than the reference's and deformed vertices within 1e-4 of it."""
+    g = golden(name)
+    v, edges, nn, P0 = g["v"], g["edges"], g["nn"], g["P0"]
+    P, st = mods["nicp"].solve(P0, g["w"], v, edges, nn, C, compat=True)
+    dd = mods["nicp"].deform(P, g["w"], v).cpu().numpy()
+    print(name, "compat: leastsq err", float(g["lsq_err"]), "gpu", st, "max |dd-ref|", np.abs(dd - g["lsq_deformed"]).max())
+    assert st["err"] <= float(g["lsq_err"]) * (1 + 1e-6)
+    np.testing.assert_allclose(dd, g["lsq_deformed"], rtol=1e-4, atol=1e-4)
+
+
+def test_nicp_outer_loop(mods):
+    g = golden("nicp_step_24")
+    v, edges, tgt, P0 = g["v"], g["edges"], g["tgt"], g["P0"]
+    nbr, wt = sparse_from_dense(g["w"])
+    run = int(g["nicp_run"])
+    # corrected mode vs the oracle's outer loop in the same mode
+    dd_o, P_o, c_o = orc.nicp(P0.copy(), nbr, wt, v, edges, tgt, 0.01, run, compat=False)
+    hist = []
+    dd, P, c = mods["nicp"].nicp(P0, g["w"], v, edges, tgt, 0.01, run, C, compat=False, history=hist)
+    assert c == c_o
+    np.testing.assert_allclose(dd.cpu().numpy(), dd_o, rtol=RTOL, atol=1e-8)
+    # reference mode vs the reference's own run (golden): schedule identical, vertices close
+    n3 = mods["nicp_3d"]
+    n3.c_fit, n3.c_rigid, n3.c_smooth = C
+    dd2, P2 = n3.NICP(P0, g["w"], v, edges, tgt, 0.01, run)
+    np.testing.assert_allclose([n3.c_fit, n3.c_rigid, n3.c_smooth], g["nicp_c"])
+    np.testing.assert_allclose(dd2, g["nicp_dd"], rtol=1e-4, atol=1e-4)
+    n3.c_fit, n3.c_rigid, n3.c_smooth = C
+
+
+def test_solve_10k_mesh_properties(mods):
+    """BASELINE config C3 size (10k-vertex mesh): size-independent properties -- weights sum
+    to 1, Deform(identity) == source, J^T(J p) is symmetric (<Jp,Jq> == <p,J^T J q>), the solve
+    decreases the energy and is deterministic run to run."""
+    nic, torch = mods["nicp"], mods["torch"]
+    v, edges, tgt = orc.make_grid_mesh(100, 100, seed=7)
+    n = v.shape[0]
+    w = nic.knn_weights(v)
+    np.testing.assert_allclose(w.sum(0), 1.0, atol=1e-13)
+    P0 = nic.initial_params(n, 3)
+    np.testing.assert_allclose(nic.deform(P0, w, v).cpu().numpy(), v, rtol=0, atol=1e-13)
+    rng = np.random.default_rng(0)
+    P = P0 + 0.01 * rng.standard_normal(P0.shape)
+    p, q = rng.standard_normal(P0.shape), rng.standard_normal(P0.shape)
+    Jp, Jq = nic.jvp(P, w, v, edges, C, p), nic.jvp(P, w, v, edges, C, q)
+    lhs = float((Jp * Jq).sum())
+    rhs = float((nic.ctx_to(p) * nic.jtvp(P, w, v, edges, C, Jq)).sum()) if hasattr(nic, "ctx_to") else \
+        float((torch.as_tensor(p, device=Jp.device) * nic.jtvp(P, w, v, edges, C, Jq)).sum())
+    assert abs(lhs - rhs) <= 1e-9 * abs(lhs)
+    idx = c_oracle.match_idx(v, tgt)[0]
+    nn = tgt[idx]
+    opts = dict(max_lm_iters=3, cg_tol=1e-6)
+    P1, st1 = nic.solve(P0, w, v, edges, nn, C, compat=False, opts=opts)
+    P2, st2 = nic.solve(P0, w, v, edges, nn, C, compat=False, opts=opts)
+    assert st1["err"] < st1["err0"]
+    assert torch.equal(P1, P2) and st1 == st2
