@@ -103,9 +103,11 @@ __global__ __launch_bounds__(NB) void knn_rows_kernel(const double *__restrict__
             // insert (r, jj) keeping (key, id) sorted ascending, stable
             double ck = r;
             int32_t ci = jj;
+            bool shifting = false;  // once placed, everything behind moves down one slot
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const bool sw = ck < key[k];
+                const bool sw = shifting || ck < key[k];
+                shifting = sw;
                 const double tk = sw ? key[k] : ck;
                 const int32_t ti = sw ? id[k] : ci;
                 key[k] = sw ? ck : key[k];

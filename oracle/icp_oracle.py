@@ -488,9 +488,11 @@ def d_min_func(P, nbr, wt, srcdata, edges, tgtdata, c=(C_FIT, C_RIGID, C_SMOOTH)
 
 
 def nicp(P, nbr, wt, source, edges, target, tol, run, c=(C_FIT, C_RIGID, C_SMOOTH), history=None,
-         compat=True):
+         compat=True, **lsq_kw):
     """nicp_3d.py:344-363: outer loop with scipy.optimize.leastsq (MINPACK lmder)
-    and the stiffness-halving schedule.  Returns (deformed, P, (c_fit,c_rigid,c_smooth))."""
+    and the stiffness-halving schedule.  Returns (deformed, P, (c_fit,c_rigid,c_smooth)).
+    lsq_kw (e.g. ftol=, xtol=) tightens MINPACK's stopping tests for solver-parity tests; the
+    reference itself uses the defaults."""
     from scipy import optimize
     c = list(c)
     source = np.asarray(source, dtype=np.float64)
@@ -503,7 +505,7 @@ def nicp(P, nbr, wt, source, edges, target, tol, run, c=(C_FIT, C_RIGID, C_SMOOT
         cc = tuple(c)
         lsq = optimize.leastsq(lambda p: min_func(p, nbr, wt, source, edges, nn, cc, compat), P,
                                Dfun=lambda p: d_min_func(p, nbr, wt, source, edges, nn, cc, compat),
-                               full_output=1)
+                               full_output=1, **lsq_kw)
         P = lsq[0]
         err = (lsq[2]['fvec'] * lsq[2]['fvec']).sum()
         if history is not None:

@@ -157,12 +157,20 @@ def test_nicp_outer_loop(mods):
     v, edges, tgt, P0 = g["v"], g["edges"], g["tgt"], g["P0"]
     nbr, wt = sparse_from_dense(g["w"])
     run = int(g["nicp_run"])
-    # corrected mode vs the oracle's outer loop in the same mode
-    dd_o, P_o, c_o = orc.nicp(P0.copy(), nbr, wt, v, edges, tgt, 0.01, run, compat=False)
+    # corrected mode vs the oracle's outer loop in the same mode.  With both solvers driven to
+    # tight convergence the minimiser is unique -> 1e-6; at leastsq's default stopping tests
+    # (ftol = xtol = 1.49e-8 on the ENERGY) each side is itself only determined to ~1e-5.
+    tight = dict(ftol=1e-15, xtol=1e-15)
+    dd_o, P_o, c_o = orc.nicp(P0.copy(), nbr, wt, v, edges, tgt, 0.01, run, compat=False, **tight)
     hist = []
-    dd, P, c = mods["nicp"].nicp(P0, g["w"], v, edges, tgt, 0.01, run, C, compat=False, history=hist)
+    dd, P, c = mods["nicp"].nicp(P0, g["w"], v, edges, tgt, 0.01, run, C, compat=False, history=hist,
+                                 opts=dict(ftol=1e-15, xtol=1e-15, cg_tol=1e-13))
     assert c == c_o
     np.testing.assert_allclose(dd.cpu().numpy(), dd_o, rtol=RTOL, atol=1e-8)
+    dd_d, _, c_d = orc.nicp(P0.copy(), nbr, wt, v, edges, tgt, 0.01, run, compat=False)
+    dd_g, _, c_g = mods["nicp"].nicp(P0, g["w"], v, edges, tgt, 0.01, run, C, compat=False)
+    assert c_d == c_g
+    np.testing.assert_allclose(dd_g.cpu().numpy(), dd_d, rtol=1e-4, atol=1e-5)
     # reference mode vs the reference's own run (golden): schedule identical, vertices close
     n3 = mods["nicp_3d"]
     n3.c_fit, n3.c_rigid, n3.c_smooth = C
