@@ -41,6 +41,9 @@ struct nicp_graph {
 
 namespace icp {
 
+int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
+                     unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done);
+
 constexpr int NB = 256;
 constexpr int KNN_TILE = 512;
 
@@ -1092,5 +1095,44 @@ extern "C" int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const do
     stt.err = f2;
     if (stats_out) *stats_out = stt;
     ICP_HIP_CHECK(hipStreamSynchronize(st));
+    return ICP_OK;
+}
+
+// NICP outer loop: nicp_3d.py:344-363 (Deform -> Match -> leastsq -> stiffness schedule).
+extern "C" int nicp_run(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, const double *tgt, int64_t m,
+                        double tol, int max_outer, double *c3_inout_host, unsigned flags,
+                        const nicp_solve_opts *opts_host, double *deformed_out, double *err_hist_host,
+                        int *outer_iters_host) {
+    ICP_REQUIRE(ctx && g && P_inout && v && tgt && c3_inout_host, "null pointer");
+    ICP_REQUIRE(m > 0 && m < 0x7fffffff && max_outer >= 0, "bad sizes");
+    ICP_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t n = g->n;
+    const int dim = g->dim;
+    if (int rc = ensure(ctx, ctx->grid_e, (size_t)n * dim * sizeof(double) * 2 + (size_t)n * sizeof(int32_t))) return rc;
+    double *dd = (double *)ctx->grid_e.ptr, *nn = dd + n * dim;
+    int32_t *idx = (int32_t *)(nn + n * dim);
+    double err = 100000000.0;  // nicp_3d.py:346
+    int it = 0;
+    for (; it < max_outer; ++it) {
+        const double e = err;
+        if (int rc = nicp_deform(ctx, g, P_inout, v, dd)) return rc;
+        if (int rc = closest_dispatch(ctx, dd, n, tgt, m, dim, 0u, idx, nullptr, nullptr)) return rc;
+        if (int rc = icp_gather_points(ctx, tgt, idx, n, dim, nn)) return rc;
+        nicp_solve_stats st;
+        if (int rc = nicp_solve(ctx, g, P_inout, v, nn, c3_inout_host, flags, opts_host, &st)) return rc;
+        err = st.err;
+        if (err_hist_host) err_hist_host[it] = err;
+        if ((e - err) < tol) {  // nicp_3d.py:355-359
+            c3_inout_host[1] /= 2.0;
+            c3_inout_host[2] /= 2.0;
+            if (c3_inout_host[1] < 0.1 || c3_inout_host[2] < 0.1) {
+                ++it;
+                break;
+            }
+        }
+    }
+    if (outer_iters_host) *outer_iters_host = it;
+    if (deformed_out)
+        if (int rc = nicp_deform(ctx, g, P_inout, v, deformed_out)) return rc;
     return ICP_OK;
 }

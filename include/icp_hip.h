@@ -190,6 +190,17 @@ int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, co
                const double *c3_host, unsigned flags, const nicp_solve_opts *opts_host,
                nicp_solve_stats *stats_host);
 
+/* NICP: nicp_3d.py:344-363 (interactive twin nicp_row.py:243-264).  Outer loop
+ * Deform -> Match -> nicp_solve; when the energy improves by less than tol, c_rigid and
+ * c_smooth are halved and the loop ends once either drops below 0.1.  c3_inout_host is
+ * updated in place (the reference mutates its module globals, nicp_3d.py:345,356-357).
+ * tgt[m,dim] is a device pointer; err_hist_host[max_outer], outer_iters_host and
+ * deformed_out[n,dim] (device) may be NULL.  Synchronises. */
+int nicp_run(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, const double *tgt, int64_t m,
+             double tol, int max_outer, double *c3_inout_host, unsigned flags,
+             const nicp_solve_opts *opts_host, double *deformed_out, double *err_hist_host,
+             int *outer_iters_host);
+
 #ifdef __cplusplus
 }
 #endif

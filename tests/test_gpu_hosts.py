@@ -1,0 +1,94 @@
+"""GPU tests of the host-side mirrors: the C++ nicp3d command core (through its Maya-free
+CLI) and the 2-D demo modules nicp_row / nicp_row_rt."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import icp_oracle as orc
+from conftest import golden, ROOT
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ROOT, "icp_amd", "nicp3d_cli")
+
+
+def write_obj(path, v, edges):
+    with open(path, "w") as f:
+        for p in v:
+            f.write("v %.17g %.17g %.17g\n" % tuple(p))
+        for a, b in edges:
+            f.write("l %d %d\n" % (a + 1, b + 1))
+
+
+def read_obj_vertices(path):
+    return np.array([[float(x) for x in ln.split()[1:4]] for ln in open(path) if ln.startswith("v ")])
+
+
+def test_nicp3d_cli_doit(tmp_path):
+    """nicp3d.cpp:67-94 as shipped: identity parameters + debug Tz = 2 -> every vertex moves
+    by (0,0,2); compared with the oracle's C++-semantics restatement."""
+    assert os.path.exists(CLI), "build icp_amd/nicp3d_cli first (make -C icp_amd/csrc)"
+    v, edges, tgt = orc.make_grid_mesh(12, 15, seed=3)
+    write_obj(tmp_path / "s.obj", v, edges)
+    write_obj(tmp_path / "t.obj", tgt, edges)
+    out = subprocess.run([CLI, str(tmp_path / "s.obj"), str(tmp_path / "t.obj"), str(tmp_path / "o.obj")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "Source mesh has %d vertics, %d edges" % (len(v), len(edges)) in out.stdout
+    dd = read_obj_vertices(tmp_path / "o.obj")
+    P, nbr, wt = orc.initialise_cxx(v)
+    np.testing.assert_allclose(dd, orc.deform(P, nbr, wt, v), rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(dd, v + np.array([0, 0, 2.0]), rtol=0, atol=1e-12)
+
+
+def test_nicp3d_cli_full_nicp(tmp_path):
+    """--nicp --fixed: the full loop through the C++ host equals the Python host's run."""
+    from icp_amd import nicp
+    g = golden("nicp_step_24")
+    v, edges, tgt = g["v"], g["edges"], g["tgt"]
+    write_obj(tmp_path / "s.obj", v, edges)
+    write_obj(tmp_path / "t.obj", tgt, [])
+    out = subprocess.run([CLI, str(tmp_path / "s.obj"), str(tmp_path / "t.obj"), str(tmp_path / "o.obj"),
+                          "--nicp", "0.01", "4", "--fixed"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    dd = read_obj_vertices(tmp_path / "o.obj")
+    w = nicp.knn_weights(v)
+    ddp, _, _ = nicp.nicp(nicp.initial_params(len(v), 3), w, v, edges, tgt, 0.01, 4, (0.1, 1000.0, 100.0), compat=False)
+    np.testing.assert_allclose(dd, ddp.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    nbr, wt = w.nbr.cpu().numpy(), w.wt.cpu().numpy()
+    dd_o, _, _ = orc.nicp(g["P0"].copy(), nbr, wt, v, edges, tgt, 0.01, 4, compat=False)
+    np.testing.assert_allclose(dd, dd_o, rtol=1e-4, atol=1e-5)
+
+
+def test_nicp_row_module():
+    from icp_amd import nicp_row
+    g = golden("nicp_row_20")
+    v, edges, nn = g["v"], g["edges"], g["nn"]
+    P0, w = nicp_row.Initialise(v, g["tgt"])
+    assert np.array_equal(P0, g["P0"])
+    np.testing.assert_allclose(w.toarray(), g["w"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(nicp_row.Deform(g["P_rand"], w, v), g["deform_rand"], rtol=1e-6)
+    np.testing.assert_allclose(nicp_row.MinFunc(g["P_rand"], w, v, edges, nn), g["r"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(nicp_row.D_MinFunc(g["P_rand"], w, v, edges, nn), g["J"], rtol=1e-6, atol=1e-9)
+    assert np.array_equal(nicp_row.Match(nicp_row.Deform(P0, w, v), g["tgt"]), nn)
+    # solve: energy no worse than the reference's leastsq result (compat Jacobian, Q7)
+    from icp_amd import nicp
+    P, st = nicp.solve(P0, w, v, edges, nn, (0.1, 1000, 100), compat=True)
+    assert st["err"] <= float(g["lsq_err"]) * (1 + 1e-6)
+
+
+def test_nicp_row_rt_module():
+    from icp_amd import nicp_row_rt as rt
+    g = golden("nicp_row_rt")
+    p = g["p"]
+    np.testing.assert_allclose(rt.Deform(g["src"], *p), g["deform"], rtol=1e-12)
+    np.testing.assert_allclose(rt.Disp(p, g["src"], g["nn"]), g["disp"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(rt.D_Disp(p, g["src"], g["nn"]), g["d_disp"], rtol=1e-12, atol=1e-15)
+    hist = rt.Solve(g["src"], g["tgt"], np.zeros(3), 6)
+    # leastsq stops at ftol = 1.49e-8 on the ENERGY, which leaves its parameters ~1e-4 away from
+    # the exact least-squares optimum the closed form returns; the energies agree to second order.
+    for (pk, ek), ref in zip(hist, g["lm_hist"]):
+        np.testing.assert_allclose(pk, ref[:3], rtol=3e-4, atol=3e-4)
+        np.testing.assert_allclose(ek, ref[3], rtol=1e-6, atol=1e-10)
+        assert ek <= ref[3] * (1 + 1e-12)
