@@ -332,24 +332,42 @@ static int launch_closest(icp_ctx *ctx, const double *src, int64_t n, const doub
     return ICP_OK;
 }
 
-// internal entry used by icp_closest and by the fused ICP loop
+// The grid pays off once the brute-force scan costs more than the build (a few launches and
+// one host sync) -- roughly a billion pair evaluations.
+bool grid_worthwhile(int64_t n, int64_t m, unsigned flags) {
+    if (flags & ICP_FORCE_BRUTE) return false;
+    if (flags & ICP_FORCE_GRID) return true;
+    return m >= 4096 && (double)n * (double)m >= 1073741824.0;
+}
+
+// internal entry used by icp_closest, the fused ICP loop and nicp_run.  `grid` (optional) is a
+// prebuilt grid over tgt; without it one is built here when that is worthwhile.
 int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
-                     unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done) {
-    if (!(flags & ICP_COMPARE_SQRT)) {
-        return dim == 3 ? launch_closest<3, false>(ctx, src, n, tgt, m, nullptr, idx_out, d2_out, done)
-                        : launch_closest<2, false>(ctx, src, n, tgt, m, nullptr, idx_out, d2_out, done);
+                     unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done,
+                     const GridBuild *grid) {
+    GridBuild local;
+    if (!grid && grid_worthwhile(n, m, flags)) {
+        if (int rc = grid_build(ctx, tgt, m, dim, local)) return rc;
+        grid = &local;
     }
+    const bool use_grid = grid && grid->usable && !(flags & ICP_FORCE_BRUTE);
+    auto argmin = [&](double *d2) -> int {
+        if (use_grid) return grid_query(ctx, *grid, src, n, nullptr, false, nullptr, idx_out, d2, done);
+        return dim == 3 ? launch_closest<3, false>(ctx, src, n, tgt, m, nullptr, idx_out, d2, done)
+                        : launch_closest<2, false>(ctx, src, n, tgt, m, nullptr, idx_out, d2, done);
+    };
+    if (!(flags & ICP_COMPARE_SQRT)) return argmin(d2_out);
     // pass 1: min d2; pass 2: lowest index inside the same rounded-sqrt class
     if (int rc = ensure(ctx, ctx->work_a, (size_t)n * sizeof(double))) return rc;
     if (int rc = ensure(ctx, ctx->work_b, (size_t)n * sizeof(double))) return rc;
     double *dmin = (double *)ctx->work_a.ptr, *thr = (double *)ctx->work_b.ptr;
-    int rc = dim == 3 ? launch_closest<3, false>(ctx, src, n, tgt, m, nullptr, idx_out, dmin, done)
-                      : launch_closest<2, false>(ctx, src, n, tgt, m, nullptr, idx_out, dmin, done);
-    if (rc) return rc;
+    if (int rc = argmin(dmin)) return rc;
     hipLaunchKernelGGL(sqrt_class_upper, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dmin, n, thr);
     ICP_HIP_CHECK(hipGetLastError());
-    rc = dim == 3 ? launch_closest<3, true>(ctx, src, n, tgt, m, thr, idx_out, nullptr, done)
-                  : launch_closest<2, true>(ctx, src, n, tgt, m, thr, idx_out, nullptr, done);
+    int rc;
+    if (use_grid) rc = grid_query(ctx, *grid, src, n, nullptr, true, thr, idx_out, nullptr, done);
+    else rc = dim == 3 ? launch_closest<3, true>(ctx, src, n, tgt, m, thr, idx_out, nullptr, done)
+                       : launch_closest<2, true>(ctx, src, n, tgt, m, thr, idx_out, nullptr, done);
     if (rc) return rc;
     if (d2_out) ICP_HIP_CHECK(hipMemcpyAsync(d2_out, dmin, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return ICP_OK;

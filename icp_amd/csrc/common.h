@@ -56,6 +56,30 @@ struct icp_ctx {
 namespace icp {
 int ensure(icp_ctx *ctx, Scratch &s, size_t bytes);
 
+// spatial grid over a target cloud (grid.hip)
+struct GridParams {
+    double mn[3];
+    double mx[3];
+    double h;      // finest cell side
+    double inv_h;
+    int bits;      // cells per axis = 1 << bits
+    int dim;
+};
+struct GridBuild {
+    GridParams gp;
+    double *spts = nullptr;     // targets in Morton order
+    int32_t *sidx = nullptr;    // their original indices
+    uint32_t *start = nullptr;  // [ncell+1] first sorted position of every finest cell
+    bool usable = false;        // false: non-finite targets -> use the brute-force scan
+};
+int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb);
+int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
+               const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done);
+int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
+                     unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done,
+                     const GridBuild *grid = nullptr);
+bool grid_worthwhile(int64_t n, int64_t m, unsigned flags);
+
 // 64-bit shuffle helpers (wave = 64 lanes)
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
     int lo = __double2loint(v), hi = __double2hiint(v);

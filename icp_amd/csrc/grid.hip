@@ -1,0 +1,424 @@
+// Exact nearest neighbour through a multi-resolution uniform grid.
+//
+// Same result as the brute-force scan of closest.hip, bit for bit: every candidate is
+// evaluated with the reference formula d2 = ((dx*dx)+(dy*dy))+(dz*dz) in fp64 without
+// FMA, candidates are compared by the total order (d2, index) -- lowest index on ties --
+// and a cell is skipped / the search stopped only when a lower bound that is provably
+// <= every computed d2 in the unvisited region is STRICTLY greater than the current best
+// (a tie would have to be visited, because it may carry a lower index).
+//
+// Why the bounds are safe in floating point: rounding is monotone.  If a target point t
+// lies in a region whose distance from the query along axis a is at least g_a (a double
+// computed with downward slack), then |fl(t_a - s_a)| >= g_a, fl(dx*dx) >= fl(g_a*g_a),
+// and adding / rounding non-negative terms keeps the inequality, so the computed d2 is
+// >= ((gx*gx)+(gy*gy))+(gz*gz) evaluated the same way.
+//
+// Structure: targets are counting-sorted by the Morton code of their finest-level cell
+// (2^b cells per axis).  A level-l cell (side h*2^l) is then the contiguous range
+// start[code << DIM*l] .. start[(code+1) << DIM*l] of the sorted array, so ONE start
+// array serves every level.  A query visits the 3^DIM neighbourhood of its cell at level
+// 0, 1, 2, ... until the best distance is below the distance to the neighbourhood's
+// boundary; sparse regions climb levels, dense regions stop at level 0.
+//
+// Targets containing NaN/inf are refused by the builder (flag) and the caller falls back
+// to the brute-force kernels, whose "first NaN wins" rule needs a full scan anyway.
+#include "common.h"
+
+namespace icp {
+
+constexpr int GB = 256;
+
+// device-side bbox record: min[3], max[3], nonfinite count
+struct BBox {
+    double mn[3], mx[3];
+    unsigned long long bad;
+};
+
+template <int DIM>
+__global__ __launch_bounds__(GB) void bbox_kernel(const double *__restrict__ p, int64_t n, double *__restrict__ partial) {
+    double mn[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
+    double mx[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
+    double bad = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * GB + threadIdx.x; i < n; i += (int64_t)gridDim.x * GB) {
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            const double v = p[i * DIM + c];
+            if (!(fabs(v) < __builtin_inf())) bad += 1.0;  // NaN or inf
+            else {
+                mn[c] = v < mn[c] ? v : mn[c];
+                mx[c] = v > mx[c] ? v : mx[c];
+            }
+        }
+    }
+    __shared__ double red[GB / 64][7];
+    const int tid = threadIdx.x;
+    double vals[7] = {mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], bad};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        double v = vals[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double w = shfl_down_f64(v, o);
+            v = k < 3 ? (w < v ? w : v) : (k < 6 ? (w > v ? w : v) : v + w);
+        }
+        if ((tid & 63) == 0) red[tid >> 6][k] = v;
+    }
+    __syncthreads();
+    if (tid < 7) {
+        double v = red[0][tid];
+        for (int w = 1; w < GB / 64; ++w) {
+            const double x = red[w][tid];
+            v = tid < 3 ? (x < v ? x : v) : (tid < 6 ? (x > v ? x : v) : v + x);
+        }
+        partial[(int64_t)blockIdx.x * 8 + tid] = v;
+    }
+}
+
+__global__ void bbox_final_kernel(const double *__restrict__ partial, int nb, BBox *__restrict__ out) {
+    const int tid = threadIdx.x;
+    if (tid >= 7) return;
+    double v = partial[tid];
+    for (int b = 1; b < nb; ++b) {
+        const double x = partial[(int64_t)b * 8 + tid];
+        v = tid < 3 ? (x < v ? x : v) : (tid < 6 ? (x > v ? x : v) : v + x);
+    }
+    if (tid < 3) out->mn[tid] = v;
+    else if (tid < 6) out->mx[tid - 3] = v;
+    else out->bad = (unsigned long long)v;
+}
+
+__device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 10 bits -> every third bit
+    x &= 0x3ff;
+    x = (x | (x << 16)) & 0x030000ff;
+    x = (x | (x << 8)) & 0x0300f00f;
+    x = (x | (x << 4)) & 0x030c30c3;
+    x = (x | (x << 2)) & 0x09249249;
+    return x;
+}
+__device__ __forceinline__ uint32_t spread2(uint32_t x) {  // 16 bits -> every second bit
+    x &= 0xffff;
+    x = (x | (x << 8)) & 0x00ff00ff;
+    x = (x | (x << 4)) & 0x0f0f0f0f;
+    x = (x | (x << 2)) & 0x33333333;
+    x = (x | (x << 1)) & 0x55555555;
+    return x;
+}
+template <int DIM>
+__device__ __forceinline__ uint32_t morton(const int *c) {
+    if (DIM == 3) return spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2);
+    return spread2(c[0]) | (spread2(c[1]) << 1);
+}
+
+template <int DIM>
+__device__ __forceinline__ void cell_of(const double *p, const GridParams &gp, int *c) {
+    const int top = (1 << gp.bits) - 1;
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) {
+        const double f = (p[a] - gp.mn[a]) * gp.inv_h;
+        int ci = f >= 0.0 ? (f < (double)top ? (int)f : top) : 0;  // NaN -> 0
+        c[a] = ci;
+    }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(GB) void cell_count_kernel(const double *__restrict__ tgt, int64_t m, GridParams gp,
+                                                       uint32_t *__restrict__ code_out, uint32_t *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * GB + threadIdx.x;
+    if (i >= m) return;
+    double p[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) p[a] = tgt[i * DIM + a];
+    int c[DIM];
+    cell_of<DIM>(p, gp, c);
+    const uint32_t code = morton<DIM>(c);
+    code_out[i] = code;
+    atomicAdd(&count[code], 1u);
+}
+
+// exclusive scan of `count[0..len)` in three passes; block sums in `bsum`
+constexpr int SCAN_ITEMS = 8;  // per thread
+__global__ __launch_bounds__(GB) void scan_block_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                       uint32_t *__restrict__ bsum, int64_t len) {
+    __shared__ uint32_t wsum[GB / 64];
+    const int tid = threadIdx.x;
+    const int64_t base = ((int64_t)blockIdx.x * GB + tid) * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], tot = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = base + k < len ? in[base + k] : 0u;
+        tot += v[k];
+    }
+    // inclusive wave scan of tot
+    uint32_t inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if ((tid & 63) >= o) inc += t;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < (tid >> 6); ++w) woff += wsum[w];
+    uint32_t run = woff + inc - tot;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < len) out[base + k] = run;
+        run += v[k];
+    }
+    if (tid == GB - 1) bsum[blockIdx.x] = woff + inc;
+}
+__global__ void scan_sums_kernel(uint32_t *__restrict__ bsum, int nb) {  // single thread-block, sequential chunks
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        uint32_t v = i < nb ? bsum[i] : 0u;
+        // block-wide exclusive scan over 1024 threads via LDS
+        __shared__ uint32_t tmp[1024];
+        tmp[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            uint32_t t = threadIdx.x >= o ? tmp[threadIdx.x - o] : 0u;
+            __syncthreads();
+            tmp[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint32_t incl = tmp[threadIdx.x];
+        if (i < nb) bsum[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(GB) void scan_add_kernel(uint32_t *__restrict__ out, const uint32_t *__restrict__ bsum,
+                                                     int64_t len, uint32_t total_at_end) {
+    const int64_t base = ((int64_t)blockIdx.x * GB + threadIdx.x) * SCAN_ITEMS;
+    const uint32_t off = bsum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < len) out[base + k] += off;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[len] = total_at_end;
+}
+
+// scatter into Morton order; `fill` is a zeroed per-cell cursor
+template <int DIM>
+__global__ __launch_bounds__(GB) void scatter_kernel(const double *__restrict__ tgt, const uint32_t *__restrict__ code,
+                                                    int64_t m, const uint32_t *__restrict__ start, uint32_t *__restrict__ fill,
+                                                    double *__restrict__ spts, int32_t *__restrict__ sidx) {
+    const int64_t i = (int64_t)blockIdx.x * GB + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t c = code[i];
+    const uint32_t pos = start[c] + atomicAdd(&fill[c], 1u);
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) spts[(int64_t)pos * DIM + a] = tgt[i * DIM + a];
+    sidx[pos] = (int32_t)i;
+}
+
+__device__ __forceinline__ bool better2(double da, int32_t ia, double db, int32_t ib) {
+    const bool an = da != da, bn = db != db;
+    if (an || bn) return (an && bn) ? (ia < ib) : an;
+    return da < db || (da == db && ia < ib);
+}
+
+// LE = false: argmin (d2, index).  LE = true: lowest index with d2 <= thr[q].
+template <int DIM, bool LE>
+__global__ __launch_bounds__(GB) void grid_query_kernel(const double *__restrict__ src, int64_t n,
+                                                       const int32_t *__restrict__ qorder,
+                                                       const double *__restrict__ spts, const int32_t *__restrict__ sidx,
+                                                       const uint32_t *__restrict__ start, GridParams gp,
+                                                       const double *__restrict__ thr_in, int32_t *__restrict__ idx_out,
+                                                       double *__restrict__ d2_out, const int32_t *__restrict__ done) {
+    if (done && *done) return;
+    const int64_t t = (int64_t)blockIdx.x * GB + threadIdx.x;
+    if (t >= n) return;
+    const int64_t q = qorder ? (int64_t)qorder[t] : t;
+    double s[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) s[a] = src[q * DIM + a];
+    int c0[DIM];
+    cell_of<DIM>(s, gp, c0);
+    double slack_abs[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) slack_abs[a] = (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
+
+    double best = __builtin_inf();
+    int32_t bi = 0x7fffffff;
+    const double thr = LE ? thr_in[q] : 0.0;
+    constexpr int NBR = DIM == 3 ? 27 : 9;
+    for (int l = 0; l <= gp.bits; ++l) {
+        const double hl = gp.h * (double)(1 << l);
+        const int ncl = 1 << (gp.bits - l);
+        const double slack_h = hl * 0x1p-20;
+        int cl[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) cl[a] = c0[a] >> l;
+        for (int nb = 0; nb < NBR; ++nb) {
+            // own cell first (offset 0,0,0), then the rest
+            const int k = nb == 0 ? NBR / 2 : (nb <= NBR / 2 ? nb - 1 : nb);
+            int off[3] = {k % 3 - 1, (k / 3) % 3 - 1, k / 9 - 1};
+            int x[DIM];
+            bool inside = true;
+            double bound = 0.0;
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) {
+                x[a] = cl[a] + off[a];
+                inside = inside && x[a] >= 0 && x[a] < ncl;
+                const double lo = gp.mn[a] + (double)x[a] * hl, hi = gp.mn[a] + (double)(x[a] + 1) * hl;
+                const double sl = slack_h + slack_abs[a];
+                double g = lo - s[a] - sl;
+                const double g2 = s[a] - hi - sl;
+                g = g2 > g ? g2 : g;
+                g = g > 0.0 ? g : 0.0;
+                bound = a == 0 ? g * g : bound + g * g;
+            }
+            if (!inside) continue;
+            if (LE ? (bound > thr) : (bound > best)) continue;
+            const uint32_t code = morton<DIM>(x);
+            const uint32_t p0 = start[(uint64_t)code << (DIM * l)], p1 = start[((uint64_t)code + 1) << (DIM * l)];
+            for (uint32_t p = p0; p < p1; ++p) {
+                double tt[DIM];
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) tt[a] = spts[(int64_t)p * DIM + a];
+                const double dx = tt[0] - s[0], dy = tt[1] - s[1];
+                double d = dx * dx + dy * dy;
+                if (DIM == 3) {
+                    const double dz = tt[2] - s[2];
+                    d = d + dz * dz;
+                }
+                const int32_t id = sidx[p];
+                if (LE) {
+                    if (d <= thr && id < bi) {
+                        bi = id;
+                        best = 0.0;
+                    }
+                } else if (better2(d, id, best, bi)) {
+                    best = d;
+                    bi = id;
+                }
+            }
+        }
+        if (ncl == 1) break;  // the neighbourhood was the whole grid
+        // distance from the query to the boundary of the visited box [cl-1, cl+1]; sides that
+        // coincide with the grid boundary have nothing beyond them
+        double mgap = __builtin_inf();
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) {
+            const double sl = slack_h + slack_abs[a];
+            if (cl[a] - 1 > 0) {
+                const double g = s[a] - (gp.mn[a] + (double)(cl[a] - 1) * hl) - sl;
+                mgap = g < mgap ? g : mgap;
+            }
+            if (cl[a] + 2 < ncl) {
+                const double g = (gp.mn[a] + (double)(cl[a] + 2) * hl) - s[a] - sl;
+                mgap = g < mgap ? g : mgap;
+            }
+        }
+        if (mgap == __builtin_inf()) break;  // box covers the grid
+        if (mgap > 0.0) {
+            const double m2 = mgap * mgap;
+            if (LE ? (thr < m2) : (best < m2)) break;
+        }
+    }
+    if (bi == 0x7fffffff) bi = 0;  // nothing comparable found (e.g. every d2 = +inf): np.argmin -> 0
+    idx_out[q] = bi;
+    if (d2_out) d2_out[q] = best;
+}
+
+// ------------------------------------------------------------------ host side
+static int env_bits() {
+    const char *e = getenv("ICP_GRID_BITS");
+    return e ? atoi(e) : 0;
+}
+
+// Builds the grid for tgt[m,dim] in ctx scratch (grid_a..grid_d).  One host sync (bbox).
+int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb) {
+    hipStream_t st = ctx->stream;
+    gb.usable = false;
+    if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
+    if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
+    double *part = (double *)ctx->partials.ptr;
+    BBox *dbox = (BBox *)((double *)ctx->small.ptr + 400);
+    int nb = (int)((m + GB - 1) / GB);
+    if (nb > 1024) nb = 1024;
+    if (dim == 3) hipLaunchKernelGGL(bbox_kernel<3>, dim3(nb), dim3(GB), 0, st, tgt, m, part);
+    else hipLaunchKernelGGL(bbox_kernel<2>, dim3(nb), dim3(GB), 0, st, tgt, m, part);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, (const double *)part, nb, dbox);
+    ICP_HIP_CHECK(hipGetLastError());
+    BBox hb;
+    ICP_HIP_CHECK(hipMemcpyAsync(&hb, dbox, sizeof(BBox), hipMemcpyDeviceToHost, st));
+    ICP_HIP_CHECK(hipStreamSynchronize(st));
+    if (hb.bad) return ICP_OK;  // NaN / inf in the target: caller uses the brute-force scan
+    double ext = 0.0;
+    for (int a = 0; a < dim; ++a) {
+        const double e = hb.mx[a] - hb.mn[a];
+        if (!(e < __builtin_inf())) return ICP_OK;  // extent overflows
+        ext = e > ext ? e : ext;
+    }
+    if (!(ext > 0.0)) ext = 1.0;  // all points identical
+    // finest level: about one cell per target point, capped by the start-array size
+    int bits = env_bits();
+    if (bits <= 0) {
+        bits = 1;
+        const int maxbits = dim == 3 ? 8 : 12;
+        while (bits < maxbits && (double)(1ull << (dim * (bits + 1))) <= 2.0 * (double)m) ++bits;
+    }
+    if (bits > (dim == 3 ? 9 : 14)) bits = dim == 3 ? 9 : 14;
+    GridParams gp;
+    for (int a = 0; a < 3; ++a) {
+        gp.mn[a] = a < dim ? hb.mn[a] : 0.0;
+        gp.mx[a] = a < dim ? hb.mx[a] : 0.0;
+    }
+    gp.bits = bits;
+    gp.dim = dim;
+    gp.h = ext / (double)(1 << bits);
+    gp.h *= 1.0 + 0x1p-30;  // the far face of the last cell lies beyond the largest coordinate
+    gp.inv_h = 1.0 / gp.h;
+    const int64_t ncell = 1ll << (dim * bits);
+    const int64_t nsb = (ncell + (int64_t)GB * SCAN_ITEMS - 1) / ((int64_t)GB * SCAN_ITEMS);
+    if (int rc = ensure(ctx, ctx->grid_a, (size_t)m * dim * sizeof(double))) return rc;   // sorted points
+    if (int rc = ensure(ctx, ctx->grid_b, (size_t)m * sizeof(int32_t) * 2)) return rc;     // sorted idx | codes
+    if (int rc = ensure(ctx, ctx->grid_c, (size_t)(ncell + 1) * sizeof(uint32_t) * 2)) return rc;  // start | count/fill
+    if (int rc = ensure(ctx, ctx->grid_d, (size_t)(nsb + 1) * sizeof(uint32_t))) return rc;
+    gb.spts = (double *)ctx->grid_a.ptr;
+    gb.sidx = (int32_t *)ctx->grid_b.ptr;
+    uint32_t *codes = (uint32_t *)ctx->grid_b.ptr + m;
+    gb.start = (uint32_t *)ctx->grid_c.ptr;
+    uint32_t *count = gb.start + (ncell + 1);
+    uint32_t *bsum = (uint32_t *)ctx->grid_d.ptr;
+    const unsigned mb = (unsigned)((m + GB - 1) / GB);
+    ICP_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(uint32_t), st));
+    if (dim == 3) hipLaunchKernelGGL(cell_count_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, m, gp, codes, count);
+    else hipLaunchKernelGGL(cell_count_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, m, gp, codes, count);
+    hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nsb), dim3(GB), 0, st, (const uint32_t *)count, gb.start, bsum, ncell);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, bsum, (int)nsb);
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nsb), dim3(GB), 0, st, gb.start, (const uint32_t *)bsum, ncell, (uint32_t)m);
+    ICP_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(uint32_t), st));
+    if (dim == 3) hipLaunchKernelGGL(scatter_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, (const uint32_t *)codes, m, (const uint32_t *)gb.start, count, gb.spts, gb.sidx);
+    else hipLaunchKernelGGL(scatter_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, (const uint32_t *)codes, m, (const uint32_t *)gb.start, count, gb.spts, gb.sidx);
+    ICP_HIP_CHECK(hipGetLastError());
+    gb.gp = gp;
+    gb.usable = true;
+    return ICP_OK;
+}
+
+int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
+               const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done) {
+    const unsigned nb = (unsigned)((n + GB - 1) / GB);
+    hipStream_t st = ctx->stream;
+#define ICP_GQ(D, L) \
+    hipLaunchKernelGGL((grid_query_kernel<D, L>), dim3(nb), dim3(GB), 0, st, src, n, qorder, (const double *)gb.spts, \
+                       (const int32_t *)gb.sidx, (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done)
+    if (gb.gp.dim == 3) {
+        if (le) ICP_GQ(3, true);
+        else ICP_GQ(3, false);
+    } else {
+        if (le) ICP_GQ(2, true);
+        else ICP_GQ(2, false);
+    }
+#undef ICP_GQ
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+}  // namespace icp

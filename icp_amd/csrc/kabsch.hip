@@ -14,9 +14,6 @@
 
 namespace icp {
 
-int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
-                     unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done);
-
 constexpr int RB = 256;  // threads per reduction block
 
 // device-resident state of one fused ICP run
@@ -510,8 +507,13 @@ extern "C" int icp_rigid_run(icp_ctx *ctx, const double *src, int64_t n, const d
     if (int rc = column_sums(ctx, tgt, m, dim, st->ct, 1)) return rc;
     ICP_HIP_CHECK(hipMemcpyAsync(ss, src, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToDevice, s));  // icp_3d.py:104
     const int32_t *done = &st->done;
+    // the target never changes inside the loop: build its search grid once
+    GridBuild grid;
+    if (grid_worthwhile(n, m, flags))
+        if (int rc = grid_build(ctx, tgt, m, dim, grid)) return rc;
+    if (!grid.usable) flags |= ICP_FORCE_BRUTE;
     for (int it = 0; it < max_iter; ++it) {
-        if (int rc = closest_dispatch(ctx, ss, n, tgt, m, dim, flags, idx, nullptr, done)) return rc;
+        if (int rc = closest_dispatch(ctx, ss, n, tgt, m, dim, flags, idx, nullptr, done, &grid)) return rc;
         if (int rc = shard_sums(ctx, src, tgt, idx, n, dim, st->cs, st->ct, st->sums, done)) return rc;
         if (int rc = kabsch_solve(ctx, st->sums, dim, st->cs, st->ct, st->R, st->t, done)) return rc;
         if (int rc = apply_err(ctx, 1, src, tgt, idx, n, dim, st->R, st->t, ss, st->sums, done)) return rc;

@@ -41,9 +41,6 @@ struct nicp_graph {
 
 namespace icp {
 
-int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
-                     unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done);
-
 constexpr int NB = 256;
 constexpr int KNN_TILE = 512;
 
@@ -1116,7 +1113,7 @@ extern "C" int nicp_run(icp_ctx *ctx, nicp_graph *g, double *P_inout, const doub
     for (; it < max_outer; ++it) {
         const double e = err;
         if (int rc = nicp_deform(ctx, g, P_inout, v, dd)) return rc;
-        if (int rc = closest_dispatch(ctx, dd, n, tgt, m, dim, 0u, idx, nullptr, nullptr)) return rc;
+        if (int rc = closest_dispatch(ctx, dd, n, tgt, m, dim, 0u, idx, nullptr, nullptr, nullptr)) return rc;
         if (int rc = icp_gather_points(ctx, tgt, idx, n, dim, nn)) return rc;
         nicp_solve_stats st;
         if (int rc = nicp_solve(ctx, g, P_inout, v, nn, c3_inout_host, flags, opts_host, &st)) return rc;

@@ -23,7 +23,8 @@ def _dims(ctx, src, tgt=None):
     return src, tgt, src.shape[1]
 
 
-def closest_indices(source, target, compare_sqrt=False, want_d2=False, force_brute=False, ctx=None):
+def closest_indices(source, target, compare_sqrt=False, want_d2=False, force_brute=False, force_grid=False,
+                    ctx=None):
     """idx[i] = argmin_j |target[j]-source[i]|^2 (bit-exact reference arithmetic,
     lowest index on ties).  Returns int32 tensor (and the fp64 d2 tensor)."""
     ctx = ctx or get_context()
@@ -36,7 +37,8 @@ def closest_indices(source, target, compare_sqrt=False, want_d2=False, force_bru
     d2 = ctx.empty((n,), torch.float64) if want_d2 else None
     if n == 0:      # Match over an empty source: nothing to launch (empty tensors have no storage)
         return (idx, d2) if want_d2 else idx
-    flags = (_lib.ICP_COMPARE_SQRT if compare_sqrt else 0) | (_lib.ICP_FORCE_BRUTE if force_brute else 0)
+    flags = ((_lib.ICP_COMPARE_SQRT if compare_sqrt else 0) | (_lib.ICP_FORCE_BRUTE if force_brute else 0) |
+             (_lib.ICP_FORCE_GRID if force_grid else 0))
     ctx.call("icp_closest", ptr(src), n, ptr(tgt), m, dim, flags, ptr(idx), ptr(d2))
     return (idx, d2) if want_d2 else idx
 
@@ -83,7 +85,7 @@ def apply_transform(source, R, t, ctx=None):
 
 
 def rigid_icp(source, target, tol, run, use_tol=True, compare_sqrt=False, force_brute=False, want_idx=False,
-              ctx=None):
+              force_grid=False, ctx=None):
     """Fused ICP loop on the device.  Returns dict(T, err_hist, iters[, idx]) of device tensors."""
     ctx = ctx or get_context()
     torch = ctx.torch
@@ -96,7 +98,8 @@ def rigid_icp(source, target, tol, run, use_tol=True, compare_sqrt=False, force_
     hist = ctx.empty((run,))
     iters = ctx.empty((1,), torch.int32)
     idx = ctx.empty((src.shape[0],), torch.int32) if want_idx else None
-    flags = (_lib.ICP_COMPARE_SQRT if compare_sqrt else 0) | (_lib.ICP_FORCE_BRUTE if force_brute else 0)
+    flags = ((_lib.ICP_COMPARE_SQRT if compare_sqrt else 0) | (_lib.ICP_FORCE_BRUTE if force_brute else 0) |
+             (_lib.ICP_FORCE_GRID if force_grid else 0))
     tolv = float(tol)
     ctx.call("icp_rigid_run", ptr(src), src.shape[0], ptr(tgt), tgt.shape[0], dim, ctypes.c_double(tolv), run,
              1 if use_tol else 0, flags, ptr(T), ptr(hist), ptr(iters), ptr(idx))

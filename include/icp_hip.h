@@ -43,7 +43,8 @@ enum {
 /* flags for icp_closest / icp_rigid_run */
 enum {
     ICP_COMPARE_SQRT = 1u, /* nicp3d.cpp:56-63,142-164: compare rounded sqrt(d2) (Q12) */
-    ICP_FORCE_BRUTE = 2u   /* never use the spatial-grid search, always scan all targets */
+    ICP_FORCE_BRUTE = 2u,  /* never use the spatial-grid search, always scan all targets */
+    ICP_FORCE_GRID = 4u    /* use the grid search whatever the problem size (tests) */
 };
 
 const char *icp_last_error(void);
@@ -69,7 +70,9 @@ int icp_memcpy_d2h(icp_ctx *ctx, void *dst_host, const void *src_dev, size_t byt
  * nicp_row.py:75-89, nicp_row_rt.py:55-69, icp.py:18-21) and nicp3d.cpp:142-164,
  * 259-272 with ICP_COMPARE_SQRT.  idx_out[i] = argmin_j ((dx*dx)+(dy*dy))+(dz*dz),
  * fp64, no FMA, lowest index on ties, first NaN wins (np.argmin).  d2_out may be
- * NULL. */
+ * NULL.  Large problems (n*m >= 2^30) are served by an exact multi-resolution grid search
+ * over the target that returns the identical indices (grid.hip); ICP_FORCE_BRUTE keeps the
+ * full scan.  The grid build synchronises the stream once. */
 int icp_closest(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
                 unsigned flags, int32_t *idx_out, double *d2_out);
 

@@ -1,0 +1,92 @@
+"""The exact grid search must return the SAME indices and squared distances as the
+brute-force scan (and the C oracle) on every kind of input: that is what makes it a legal
+replacement for the reference's O(N*M) Closest loop."""
+import numpy as np
+import pytest
+
+import c_oracle
+import icp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rigid():
+    import torch
+    assert torch.cuda.is_available()
+    from icp_amd import rigid
+    return rigid
+
+
+def both(rigid, src, tgt, **kw):
+    gi, gd = rigid.closest_indices(src, tgt, want_d2=True, force_grid=True, **kw)
+    bi, bd = rigid.closest_indices(src, tgt, want_d2=True, force_brute=True, **kw)
+    return gi.cpu().numpy(), gd.cpu().numpy(), bi.cpu().numpy(), bd.cpu().numpy()
+
+
+def clouds():
+    rng = np.random.default_rng(21)
+    out = {}
+    out["normal3"] = (rng.standard_normal((30000, 3)), rng.standard_normal((40000, 3)))
+    out["uniform2"] = (rng.uniform(-1, 1, (20000, 2)), rng.uniform(-1, 1, (9000, 2)))
+    # clustered target, queries partly far outside the target's bounding box
+    cl = np.concatenate([rng.standard_normal((20000, 3)) * 0.01 + c for c in rng.uniform(-5, 5, (8, 3))])
+    out["clustered_outside"] = (np.concatenate([rng.uniform(-20, 20, (5000, 3)), cl[:5000] + 1e-3]), cl)
+    # lattice with duplicates: masses of exact ties, lowest index must win
+    g = np.stack(np.meshgrid(np.arange(20.), np.arange(20.), np.arange(20.), indexing="ij"), -1).reshape(-1, 3)
+    tg = np.concatenate([g[rng.permutation(len(g))], g[rng.permutation(len(g))]])
+    out["lattice_ties"] = (np.concatenate([g[:3000] + 0.5, g[:3000] + [0.5, 0, 0], g[:2000], rng.uniform(-3, 23, (3000, 3))]), tg)
+    # strongly anisotropic (a thin sheet) and far from the origin (bounds carry absolute slack)
+    sheet = rng.uniform(0, 1, (30000, 3)) * [100.0, 1.0, 1e-3]
+    out["sheet"] = (sheet[:8000] + rng.standard_normal((8000, 3)) * [1.0, 0.01, 1e-4], sheet)
+    far = rng.standard_normal((20000, 3)) + 1e9
+    out["far_origin"] = (far[:6000] + rng.standard_normal((6000, 3)) * 0.1, far)
+    # all targets identical / collinear: degenerate boxes
+    out["identical"] = (rng.standard_normal((500, 3)), np.tile([[1.0, 2.0, 3.0]], (5000, 1)))
+    line = np.zeros((5000, 3))
+    line[:, 0] = np.linspace(0, 1, 5000)
+    out["collinear"] = (rng.standard_normal((2000, 3)), line)
+    out["tiny_target"] = (rng.standard_normal((3000, 3)), rng.standard_normal((3, 3)))
+    return out
+
+
+@pytest.mark.parametrize("name", list(clouds().keys()))
+def test_grid_equals_bruteforce(rigid, name):
+    src, tgt = clouds()[name]
+    gi, gd, bi, bd = both(rigid, src, tgt)
+    assert np.array_equal(gi, bi), "%s: %d index mismatches" % (name, (gi != bi).sum())
+    assert np.array_equal(gd, bd)
+    oi, od = c_oracle.match_idx(src, tgt)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+
+
+def test_grid_compare_sqrt(rigid):
+    rng = np.random.default_rng(5)
+    tgt = np.concatenate([rng.standard_normal((8000, 3)), [[1.0, 2.0 ** -26, 0.0], [1.0, 0.0, 0.0]]])
+    src = np.concatenate([rng.standard_normal((4000, 3)) * 1e-9, rng.standard_normal((4000, 3))])
+    gi, gd, bi, bd = both(rigid, src, tgt, compare_sqrt=True)
+    oi, _ = c_oracle.match_idx(src, tgt, compare_sqrt=True)
+    assert np.array_equal(gi, oi) and np.array_equal(bi, oi)
+
+
+def test_grid_nonfinite_falls_back(rigid):
+    rng = np.random.default_rng(6)
+    tgt = rng.standard_normal((6000, 3))
+    tgt[4321, 2] = np.nan
+    src = rng.standard_normal((3000, 3))
+    gi, gd, bi, bd = both(rigid, src, tgt)                 # builder refuses -> brute force -> first NaN wins
+    assert np.array_equal(gi, np.full(3000, 4321)) and np.array_equal(bi, gi)
+    tgt = rng.standard_normal((6000, 3))
+    src[7] = np.nan                                        # NaN QUERY: every d2 is NaN -> index 0
+    src[8, 0] = np.inf
+    gi, gd, bi, bd = both(rigid, src, tgt)
+    assert np.array_equal(gi, bi) and gi[7] == 0
+
+
+def test_grid_inside_icp(rigid):
+    src, tgt = orc.make_rigid_cloud(50000, seed=12)
+    a = rigid.rigid_icp(src, tgt, 0.10, 50, want_idx=True, force_grid=True)
+    b = rigid.rigid_icp(src, tgt, 0.10, 50, want_idx=True, force_brute=True)
+    assert int(a["iters"].cpu()[0]) == int(b["iters"].cpu()[0])
+    assert np.array_equal(a["idx"].cpu().numpy(), b["idx"].cpu().numpy())
+    assert np.array_equal(a["T"].cpu().numpy(), b["T"].cpu().numpy())     # identical indices -> identical sums
