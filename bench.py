@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32768)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--brute", action="store_true", help="force the brute-force closest-point kernel")
+    ap.add_argument("--roofline-brute", action="store_true", help="also time one brute-force launch (adds ~1 s)")
     args = ap.parse_args()
 
     import torch
@@ -126,20 +127,53 @@ def main():
         src_d, tgt_d = st.src, st.tgt
 
     # ---- dominant kernel, timed live with HIP events on the launch stream ----
+    # Default path: the exact grid search (grid_query_kernel; the target grid is built once and the
+    # queries are in Morton order, as inside icp_rigid_run).  --brute: the full-scan kernel.
     n_loc = src_d.shape[0]
     idx = ctx.empty((n_loc,), torch.int32)
-    reps = max(2, min(K, 5))
-    ctx.call("icp_closest", ptr(src_d), n_loc, ptr(tgt_d), n, 3, flags, ptr(idx), ptr(None))
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for _ in range(reps):
-        ctx.call("icp_closest", ptr(src_d), n_loc, ptr(tgt_d), n, 3, flags, ptr(idx), ptr(None))
-    ev1.record()
-    torch.cuda.synchronize()
-    t_kernel = ev0.elapsed_time(ev1) * 1e-3 / reps
-    flop = 8.0 * n_loc * n                      # 3 sub + 3 mul + 2 add per source-target pair
-    achieved = flop / t_kernel / 1e12
+
+    def time_closest(fl, reps):
+        ctx.call("icp_closest", ptr(src_d), n_loc, ptr(tgt_d), n, 3, fl, ptr(idx), ptr(None))
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(reps):
+            ctx.call("icp_closest", ptr(src_d), n_loc, ptr(tgt_d), n, 3, fl, ptr(idx), ptr(None))
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) * 1e-3 / reps
+
+    pairs = float(n_loc) * n
     compulsory = 24.0 * n_loc + 24.0 * n + 4.0 * n_loc
+    t_brute = time_closest(_lib.ICP_FORCE_BRUTE, 2) if (args.brute or args.roofline_brute) else None
+    # per-launch time of the kernel the timed loop spent its time in
+    if args.brute:
+        t_kernel = t_brute
+    else:
+        t_kernel = rigid.time_grid_query(src_d, tgt_d, reps=max(3, min(K, 10)), ctx=ctx)
+    if args.brute:
+        achieved = 8.0 * pairs / t_kernel / 1e12
+        roof = {"bound": "valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                "kernel": "closest_tiles<3,4,false>", "kernel_ms": t_kernel * 1e3,
+                "note": "8 fp64 flop per source-target pair x %.3g pairs per launch; peak = MI355X fp64 VECTOR peak "
+                        "(FMA-rated; the reference arithmetic forbids FMA so <= 39.3, and 9 instructions per 8 flop => "
+                        "ceiling ~35 TFLOP/s); VALU-bound, compulsory HBM bytes %.1f MB" % (pairs, compulsory / 1e6)}
+    else:
+        gbytes = 24.0 * n_loc + 4.0 * n_loc + 32.0 * n + 4.0 * (1 << 21)   # queries + idx out + 32-B target records + cell-start array
+        achieved = gbytes / t_kernel / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "grid_query_kernel<3,false>", "kernel_ms": t_kernel * 1e3,
+                "note": "exact grid search: algorithmic bytes per launch = 24 B/query + 4 B/index out + 32 B/target record "
+                        "(Morton-sorted, read at least once) + the 2^21-entry cell-start array = %.1f MB; "
+                        "the kernel is cache-latency-bound (gathers from the L2/MALL-resident sorted target), so the "
+                        "HBM fraction is low by construction; equivalent brute-force rate = %.3g pair-evaluations/s"
+                        % (gbytes / 1e6, pairs / t_kernel)}
+        if t_brute is not None:
+            ab = 8.0 * pairs / t_brute / 1e12
+            roof["bruteforce_kernel"] = {"bound": "valu", "achieved": ab, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                                         "unit": "TFLOP/s", "frac": ab / FP64_VECTOR_PEAK_TFLOPS,
+                                         "kernel": "closest_tiles<3,4,false>", "kernel_ms": t_brute * 1e3}
 
     if rank == 0:
         out = {
@@ -158,18 +192,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "C2: rigid ICP, 2^20 source x 2^20 target fp64 points (N(0,1)^3, seed 1, Rz(0.3)+shift, permuted), "
                                    "source rows sharded over %d GPU(s), target replicated" % world,
-                       "n_source": n, "n_target": n, "dim": 3, "search": "brute-force exact" if True else "",
+                       "n_source": n, "n_target": n, "dim": 3, "search": "brute-force scan" if args.brute else "exact multi-resolution grid (bit-identical to the scan)",
                        "last_err": err_last},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "closest_tiles<3,Q,false> (+closest_merge when the target is split)",
-                         "kernel_ms": t_kernel * 1e3,
-                         "note": "algorithmic work = 8 fp64 flop per source-target pair x N_src_local*N_tgt pairs per launch; "
-                                 "peak = MI355X fp64 VECTOR peak (FMA-rated 78.6 TFLOP/s; the reference arithmetic forbids FMA, so "
-                                 "<=39.3 is reachable and the compare makes it 9 instr/pair => ceiling ~35); the kernel is "
-                                 "VALU-bound, not HBM- or MFMA-bound (compulsory HBM bytes per launch = %.1f MB => %.3f GB/s, "
-                                 "%.5f of the 8 TB/s HBM peak)" % (compulsory / 1e6, compulsory / t_kernel / 1e9,
-                                                                  compulsory / t_kernel / 1e9 / HBM_PEAK_GBS)},
+            "roofline": roof,
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(src, tgt, min(args.cpu_sample, n))

@@ -36,6 +36,10 @@ _SIGNATURES = {
     "icp_memcpy_h2d": [c_dp, c_dp, c_dp, ctypes.c_size_t],
     "icp_memcpy_d2h": [c_dp, c_dp, c_dp, ctypes.c_size_t],
     "icp_closest": [c_dp, c_dp, c_i64, c_dp, c_i64, c_int, c_u32, c_dp, c_dp],
+    "icp_target_create": [c_dp, c_dp, c_i64, c_int, ctypes.POINTER(ctypes.c_void_p)],
+    "icp_target_destroy": [c_dp, c_dp],
+    "icp_closest_target": [c_dp, c_dp, c_dp, c_i64, c_u32, c_dp, c_dp],
+    "icp_morton_sort": [c_dp, c_dp, c_i64, c_int, c_dp, c_dp],
     "icp_gather_points": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp],
     "icp_distance_sum": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp],
     "icp_find_transform": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_dp],
@@ -45,6 +49,7 @@ _SIGNATURES = {
     "icp_kabsch_solve": [c_dp, c_dp, c_int, c_dp, c_dp, c_dp, c_dp],
     "icp_shard_apply_err": [c_dp, c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_dp, c_dp, c_dp],
     "icp_column_sums": [c_dp, c_dp, c_i64, c_int, c_dp],
+    "icp_bench_grid_query": [c_dp, c_dp, c_i64, c_dp, c_i64, c_int, c_int, c_dp],
     "nicp_knn": [c_dp, c_dp, c_i64, c_int, c_dp, c_i64, c_int, c_dp, c_dp],
     "nicp_knn_weights": [c_dp, c_dp, c_i64, c_int, c_int, c_dp, c_dp],
     "nicp_graph_create": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_i64, c_int, ctypes.POINTER(ctypes.c_void_p)],

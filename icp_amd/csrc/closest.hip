@@ -384,3 +384,70 @@ extern "C" int icp_closest(icp_ctx *ctx, const double *src, int64_t n, const dou
     ICP_HIP_CHECK(hipSetDevice(ctx->device));
     return icp::closest_dispatch(ctx, src, n, tgt, m, dim, flags, idx_out, d2_out, nullptr);
 }
+
+// ------------------------------------------------------------------ persistent target index
+struct icp_target {
+    const double *tgt;
+    int64_t m;
+    int dim;
+    icp::GridBuild grid;
+    icp::Scratch a, b, c, d;
+};
+
+extern "C" int icp_target_create(icp_ctx *ctx, const double *tgt, int64_t m, int dim, icp_target **out) {
+    ICP_REQUIRE(ctx && tgt && out, "null pointer");
+    ICP_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
+    ICP_REQUIRE(m > 0 && m < 0x7fffffff, "need 0 < m < 2^31");
+    ICP_HIP_CHECK(hipSetDevice(ctx->device));
+    icp_target *t = new icp_target();
+    t->tgt = tgt;
+    t->m = m;
+    t->dim = dim;
+    if (m >= 1024) {
+        if (int rc = icp::grid_build_into(ctx, tgt, m, dim, t->grid, t->a, t->b, t->c, t->d)) {
+            delete t;
+            return rc;
+        }
+    }
+    *out = t;
+    return ICP_OK;
+}
+
+extern "C" int icp_target_destroy(icp_ctx *ctx, icp_target *t) {
+    if (!t) return ICP_OK;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    icp::Scratch *all[] = {&t->a, &t->b, &t->c, &t->d};
+    for (icp::Scratch *s : all)
+        if (s->ptr) (void)hipFree(s->ptr);
+    delete t;
+    return ICP_OK;
+}
+
+extern "C" int icp_closest_target(icp_ctx *ctx, const icp_target *t, const double *src, int64_t n, unsigned flags,
+                                  int32_t *idx_out, double *d2_out) {
+    ICP_REQUIRE(ctx && t && src && idx_out, "null pointer");
+    ICP_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return ICP_OK;
+    ICP_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!t->grid.usable) flags |= ICP_FORCE_BRUTE;
+    return icp::closest_dispatch(ctx, src, n, t->tgt, t->m, t->dim, flags, idx_out, d2_out, nullptr, &t->grid);
+}
+
+extern "C" int icp_morton_sort(icp_ctx *ctx, const double *pts, int64_t n, int dim, double *sorted_out, int32_t *order_out) {
+    ICP_REQUIRE(ctx && pts && sorted_out && order_out, "null pointer");
+    ICP_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
+    ICP_REQUIRE(n > 0 && n < 0x7fffffff, "need 0 < n < 2^31");
+    ICP_HIP_CHECK(hipSetDevice(ctx->device));
+    icp::GridBuild g;
+    if (int rc = icp::grid_build(ctx, pts, n, dim, g, 1)) return rc;
+    if (!g.usable) {
+        icp::set_error("icp_morton_sort: non-finite coordinates");
+        return ICP_ERR_UNSUPPORTED;
+    }
+    ICP_HIP_CHECK(hipMemcpyAsync(sorted_out, g.spts, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ICP_HIP_CHECK(hipMemcpyAsync(order_out, g.sidx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    return ICP_OK;
+}

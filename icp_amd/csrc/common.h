@@ -50,7 +50,8 @@ struct icp_ctx {
     icp::Scratch partials;              // reductions: [kMaxPartials][kSumSlots] doubles
     icp::Scratch small;                 // small fp64 state (sums, means, R, t, flags)
     icp::Scratch work_a, work_b, work_c, work_d;  // general work arrays
-    icp::Scratch grid_a, grid_b, grid_c, grid_d, grid_e;  // spatial grid
+    icp::Scratch grid_a, grid_b, grid_c, grid_d, grid_e;  // spatial grid over the target
+    icp::Scratch sort_a, sort_b, sort_c, sort_d;          // Morton order of the queries
 };
 
 namespace icp {
@@ -69,10 +70,15 @@ struct GridBuild {
     GridParams gp;
     double *spts = nullptr;     // targets in Morton order
     int32_t *sidx = nullptr;    // their original indices
+    void *recs = nullptr;       // the same as 32-byte records {x, y, z, index} (double4)
     uint32_t *start = nullptr;  // [ncell+1] first sorted position of every finest cell
     bool usable = false;        // false: non-finite targets -> use the brute-force scan
 };
-int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb);
+// slot 0: target grid (grid_* scratch); slot 1: query ordering (sort_* scratch)
+int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, int slot = 0);
+// same, into caller-owned scratch (persistent target handles)
+int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, Scratch &sa, Scratch &sb,
+                    Scratch &sc, Scratch &sd);
 int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
                const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done);
 int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,

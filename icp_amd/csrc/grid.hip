@@ -74,17 +74,24 @@ __global__ __launch_bounds__(GB) void bbox_kernel(const double *__restrict__ p, 
     }
 }
 
+// one wave per quantity (7 waves): strided pass over the block partials, then a shuffle tree
 __global__ void bbox_final_kernel(const double *__restrict__ partial, int nb, BBox *__restrict__ out) {
-    const int tid = threadIdx.x;
-    if (tid >= 7) return;
-    double v = partial[tid];
-    for (int b = 1; b < nb; ++b) {
-        const double x = partial[(int64_t)b * 8 + tid];
-        v = tid < 3 ? (x < v ? x : v) : (tid < 6 ? (x > v ? x : v) : v + x);
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (k >= 7) return;
+    double v = k < 3 ? __builtin_inf() : (k < 6 ? -__builtin_inf() : 0.0);
+    for (int b = lane; b < nb; b += 64) {
+        const double x = partial[(int64_t)b * 8 + k];
+        v = k < 3 ? (x < v ? x : v) : (k < 6 ? (x > v ? x : v) : v + x);
     }
-    if (tid < 3) out->mn[tid] = v;
-    else if (tid < 6) out->mx[tid - 3] = v;
-    else out->bad = (unsigned long long)v;
+    for (int o = 32; o > 0; o >>= 1) {
+        const double x = shfl_down_f64(v, o);
+        v = k < 3 ? (x < v ? x : v) : (k < 6 ? (x > v ? x : v) : v + x);
+    }
+    if (lane == 0) {
+        if (k < 3) out->mn[k] = v;
+        else if (k < 6) out->mx[k - 3] = v;
+        else out->bad = (unsigned long long)v;
+    }
 }
 
 __device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 10 bits -> every third bit
@@ -205,11 +212,20 @@ __global__ __launch_bounds__(GB) void scan_add_kernel(uint32_t *__restrict__ out
 template <int DIM>
 __global__ __launch_bounds__(GB) void scatter_kernel(const double *__restrict__ tgt, const uint32_t *__restrict__ code,
                                                     int64_t m, const uint32_t *__restrict__ start, uint32_t *__restrict__ fill,
-                                                    double *__restrict__ spts, int32_t *__restrict__ sidx) {
+                                                    double *__restrict__ spts, int32_t *__restrict__ sidx,
+                                                    double4 *__restrict__ recs) {
     const int64_t i = (int64_t)blockIdx.x * GB + threadIdx.x;
     if (i >= m) return;
     const uint32_t c = code[i];
     const uint32_t pos = start[c] + atomicAdd(&fill[c], 1u);
+    // one 32-byte record per target: coordinates + the original index in the 4th slot, so a
+    // candidate costs two 16-byte loads from a single cache line
+    double4 rec;
+    rec.x = tgt[i * DIM];
+    rec.y = tgt[i * DIM + 1];
+    rec.z = DIM == 3 ? tgt[i * DIM + 2] : 0.0;
+    rec.w = __longlong_as_double((long long)i);
+    recs[pos] = rec;
 #pragma unroll
     for (int a = 0; a < DIM; ++a) spts[(int64_t)pos * DIM + a] = tgt[i * DIM + a];
     sidx[pos] = (int32_t)i;
@@ -225,13 +241,16 @@ __device__ __forceinline__ bool better2(double da, int32_t ia, double db, int32_
 template <int DIM, bool LE>
 __global__ __launch_bounds__(GB) void grid_query_kernel(const double *__restrict__ src, int64_t n,
                                                        const int32_t *__restrict__ qorder,
-                                                       const double *__restrict__ spts, const int32_t *__restrict__ sidx,
+                                                       const double4 *__restrict__ recs,
                                                        const uint32_t *__restrict__ start, GridParams gp,
                                                        const double *__restrict__ thr_in, int32_t *__restrict__ idx_out,
-                                                       double *__restrict__ d2_out, const int32_t *__restrict__ done) {
+                                                       double *__restrict__ d2_out, const int32_t *__restrict__ done,
+                                                       long long *__restrict__ dbg) {
     if (done && *done) return;
     const int64_t t = (int64_t)blockIdx.x * GB + threadIdx.x;
     if (t >= n) return;
+    const long long t_begin = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    int dbg_levels = 0, dbg_cand = 0;
     const int64_t q = qorder ? (int64_t)qorder[t] : t;
     double s[DIM];
 #pragma unroll
@@ -245,56 +264,148 @@ __global__ __launch_bounds__(GB) void grid_query_kernel(const double *__restrict
     double best = __builtin_inf();
     int32_t bi = 0x7fffffff;
     const double thr = LE ? thr_in[q] : 0.0;
+    // Targets are finite (the builder refuses others).  A query with a NaN / inf coordinate
+    // therefore sees d2 = NaN (or +inf) against EVERY target, and np.argmin of a constant
+    // NaN / inf array is index 0.  For finite queries no d2 can be NaN, so the plain
+    // (d2, index) comparison below is the whole of np.argmin's order.
+    {
+        bool finite = true, isnan = false;
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) {
+            finite = finite && fabs(s[a]) < __builtin_inf();
+            isnan = isnan || s[a] != s[a];
+        }
+        if (!finite) {
+            idx_out[q] = 0;
+            if (d2_out) d2_out[q] = LE ? __builtin_inf() : (isnan ? __builtin_nan("") : __builtin_inf());
+            return;
+        }
+    }
     constexpr int NBR = DIM == 3 ? 27 : 9;
+    // Per-lane work list of candidate ranges in LDS ([slot][lane] layout: conflict-free).  Lanes of
+    // a wave need different neighbour cells with different populations; walking the 27 cells in
+    // lockstep would cost (cells x longest range) trips per wave.  Instead each lane first lists
+    // the ranges that survive its bound test, then all lanes walk their OWN concatenated list, so
+    // a wave's trip count is the longest TOTAL, not the sum of per-cell maxima.
+    constexpr int LIST = 8;
+    __shared__ uint2 wl[LIST][GB];
+    const int lane_slot = threadIdx.x;
+
+    auto eval = [&](const double4 &rc) {
+        const double dx = rc.x - s[0], dy = rc.y - s[1];
+        double d = dx * dx + dy * dy;
+        if (DIM == 3) {
+            const double dz = rc.z - s[2];
+            d = d + dz * dz;
+        }
+        const int32_t id = (int32_t)__double_as_longlong(rc.w);
+        if (LE) {
+            if (d <= thr && id < bi) {
+                bi = id;
+                best = 0.0;
+            }
+        } else if (d < best || (d == best && id < bi)) {
+            best = d;
+            bi = id;
+        }
+    };
+    auto scan = [&](uint32_t p0, uint32_t p1) {
+        for (uint32_t p = p0; p < p1; p += 4) {
+            double4 rc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rc[u] = recs[p + u < p1 ? p + u : p1 - 1];  // re-reads are idempotent
+#pragma unroll
+            for (int u = 0; u < 4; ++u) eval(rc[u]);
+        }
+    };
+
     for (int l = 0; l <= gp.bits; ++l) {
+        ++dbg_levels;
         const double hl = gp.h * (double)(1 << l);
         const int ncl = 1 << (gp.bits - l);
         const double slack_h = hl * 0x1p-20;
         int cl[DIM];
+        // per axis and column offset (-1, 0, +1): squared gap (monotone-safe lower bound), validity
+        // and the column's Morton bits -- everything a neighbour cell needs is then a static pick
+        double g2[DIM][3];
+        bool okc[DIM][3];
+        uint32_t sp[DIM][3];
 #pragma unroll
-        for (int a = 0; a < DIM; ++a) cl[a] = c0[a] >> l;
-        for (int nb = 0; nb < NBR; ++nb) {
-            // own cell first (offset 0,0,0), then the rest
-            const int k = nb == 0 ? NBR / 2 : (nb <= NBR / 2 ? nb - 1 : nb);
-            int off[3] = {k % 3 - 1, (k / 3) % 3 - 1, k / 9 - 1};
-            int x[DIM];
-            bool inside = true;
-            double bound = 0.0;
+        for (int a = 0; a < DIM; ++a) {
+            cl[a] = c0[a] >> l;
+            const double sl = slack_h + slack_abs[a];
 #pragma unroll
-            for (int a = 0; a < DIM; ++a) {
-                x[a] = cl[a] + off[a];
-                inside = inside && x[a] >= 0 && x[a] < ncl;
-                const double lo = gp.mn[a] + (double)x[a] * hl, hi = gp.mn[a] + (double)(x[a] + 1) * hl;
-                const double sl = slack_h + slack_abs[a];
+            for (int o = 0; o < 3; ++o) {
+                const int x = cl[a] + o - 1;
+                okc[a][o] = x >= 0 && x < ncl;
+                sp[a][o] = okc[a][o] ? (DIM == 3 ? spread3((uint32_t)x) : spread2((uint32_t)x)) << a : 0u;
+                const double lo = gp.mn[a] + (double)x * hl, hi = gp.mn[a] + (double)(x + 1) * hl;
                 double g = lo - s[a] - sl;
-                const double g2 = s[a] - hi - sl;
-                g = g2 > g ? g2 : g;
+                const double gh = s[a] - hi - sl;
+                g = gh > g ? gh : g;
                 g = g > 0.0 ? g : 0.0;
-                bound = a == 0 ? g * g : bound + g * g;
+                g2[a][o] = g * g;
             }
-            if (!inside) continue;
-            if (LE ? (bound > thr) : (bound > best)) continue;
-            const uint32_t code = morton<DIM>(x);
-            const uint32_t p0 = start[(uint64_t)code << (DIM * l)], p1 = start[((uint64_t)code + 1) << (DIM * l)];
-            for (uint32_t p = p0; p < p1; ++p) {
-                double tt[DIM];
+        }
+        // phase A: the query's own cell (every lane has one: coherent)
+        {
+            uint32_t code = sp[0][1] | sp[1][1];
+            if (DIM == 3) code |= sp[2][1];
+            scan(start[(uint64_t)code << (DIM * l)], start[((uint64_t)code + 1) << (DIM * l)]);
+        }
+        // phase B: which neighbour cells can still hold a better (or tying) point?
+        uint32_t mask = 0;
 #pragma unroll
-                for (int a = 0; a < DIM; ++a) tt[a] = spts[(int64_t)p * DIM + a];
-                const double dx = tt[0] - s[0], dy = tt[1] - s[1];
-                double d = dx * dx + dy * dy;
-                if (DIM == 3) {
-                    const double dz = tt[2] - s[2];
-                    d = d + dz * dz;
+        for (int nb = 0; nb < NBR; ++nb) {
+            if (nb == NBR / 2) continue;
+            const int ox = nb % 3, oy = (nb / 3) % 3, oz = nb / 9;
+            bool inside = okc[0][ox] && okc[1][oy];
+            double bound = g2[0][ox] + g2[1][oy];
+            if (DIM == 3) {
+                inside = inside && okc[2][oz];
+                bound = bound + g2[2][oz];
+            }
+            if (inside && !(LE ? (bound > thr) : (bound > best))) mask |= 1u << nb;
+        }
+        // phase C: fetch the ranges of up to LIST surviving cells in one batch, then every lane walks
+        // its own concatenated list
+        while (__builtin_amdgcn_ballot_w64(mask != 0) != 0) {
+            uint32_t r0[LIST], r1[LIST];
+#pragma unroll
+            for (int k = 0; k < LIST; ++k) {
+                const bool have = mask != 0;
+                const int nb = have ? __builtin_ctz(mask) : 0;
+                mask &= mask - 1;
+                const int ox = nb % 3, oy = (nb / 3) % 3, oz = nb / 9;
+                uint32_t code = (ox == 0 ? sp[0][0] : (ox == 1 ? sp[0][1] : sp[0][2])) |
+                                (oy == 0 ? sp[1][0] : (oy == 1 ? sp[1][1] : sp[1][2]));
+                if (DIM == 3) code |= (oz == 0 ? sp[2][0] : (oz == 1 ? sp[2][1] : sp[2][2]));
+                code = have ? code : 0u;  // exhausted mask: columns -1 may be outside the grid
+                r0[k] = start[(uint64_t)code << (DIM * l)];
+                r1[k] = have ? start[((uint64_t)code + 1) << (DIM * l)] : r0[k];
+            }
+#pragma unroll
+            for (int k = 0; k < LIST; ++k) wl[k][lane_slot] = make_uint2(r0[k], r1[k]);
+            constexpr int UNR = 4;
+            int cur = 0;
+            uint32_t p = 0, pe = 0;
+            while (true) {
+                while (p >= pe && cur < LIST) {
+                    const uint2 r = wl[cur][lane_slot];
+                    ++cur;
+                    p = r.x;
+                    pe = r.y;
                 }
-                const int32_t id = sidx[p];
-                if (LE) {
-                    if (d <= thr && id < bi) {
-                        bi = id;
-                        best = 0.0;
-                    }
-                } else if (better2(d, id, best, bi)) {
-                    best = d;
-                    bi = id;
+                const bool work = p < pe;
+                if (__builtin_amdgcn_ballot_w64(work) == 0) break;
+                if (work) {
+                    double4 rc[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) rc[u] = recs[p + u < pe ? p + u : pe - 1];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) eval(rc[u]);
+                    p += UNR;
+                    dbg_cand += UNR;
                 }
             }
         }
@@ -320,6 +431,12 @@ __global__ __launch_bounds__(GB) void grid_query_kernel(const double *__restrict
             if (LE ? (thr < m2) : (best < m2)) break;
         }
     }
+    if (dbg) {
+        const long long dt = (long long)__builtin_amdgcn_s_memtime() - t_begin;
+        dbg[t * 3] = dt;
+        dbg[t * 3 + 1] = dbg_levels;
+        dbg[t * 3 + 2] = dbg_cand;
+    }
     if (bi == 0x7fffffff) bi = 0;  // nothing comparable found (e.g. every d2 = +inf): np.argmin -> 0
     idx_out[q] = bi;
     if (d2_out) d2_out[q] = best;
@@ -332,7 +449,13 @@ static int env_bits() {
 }
 
 // Builds the grid for tgt[m,dim] in ctx scratch (grid_a..grid_d).  One host sync (bbox).
-int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb) {
+int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, int slot) {
+    if (slot) return grid_build_into(ctx, tgt, m, dim, gb, ctx->sort_a, ctx->sort_b, ctx->sort_c, ctx->sort_d);
+    return grid_build_into(ctx, tgt, m, dim, gb, ctx->grid_a, ctx->grid_b, ctx->grid_c, ctx->grid_d);
+}
+
+int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, Scratch &sa, Scratch &sb,
+                    Scratch &sc, Scratch &sd) {
     hipStream_t st = ctx->stream;
     gb.usable = false;
     if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
@@ -343,7 +466,7 @@ int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &g
     if (nb > 1024) nb = 1024;
     if (dim == 3) hipLaunchKernelGGL(bbox_kernel<3>, dim3(nb), dim3(GB), 0, st, tgt, m, part);
     else hipLaunchKernelGGL(bbox_kernel<2>, dim3(nb), dim3(GB), 0, st, tgt, m, part);
-    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, (const double *)part, nb, dbox);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(448), 0, st, (const double *)part, nb, dbox);
     ICP_HIP_CHECK(hipGetLastError());
     BBox hb;
     ICP_HIP_CHECK(hipMemcpyAsync(&hb, dbox, sizeof(BBox), hipMemcpyDeviceToHost, st));
@@ -361,7 +484,7 @@ int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &g
     if (bits <= 0) {
         bits = 1;
         const int maxbits = dim == 3 ? 8 : 12;
-        while (bits < maxbits && (double)(1ull << (dim * (bits + 1))) <= 2.0 * (double)m) ++bits;
+        while (bits < maxbits && (double)(1ull << (dim * (bits + 1))) <= 4.0 * (double)m) ++bits;
     }
     if (bits > (dim == 3 ? 9 : 14)) bits = dim == 3 ? 9 : 14;
     GridParams gp;
@@ -376,16 +499,17 @@ int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &g
     gp.inv_h = 1.0 / gp.h;
     const int64_t ncell = 1ll << (dim * bits);
     const int64_t nsb = (ncell + (int64_t)GB * SCAN_ITEMS - 1) / ((int64_t)GB * SCAN_ITEMS);
-    if (int rc = ensure(ctx, ctx->grid_a, (size_t)m * dim * sizeof(double))) return rc;   // sorted points
-    if (int rc = ensure(ctx, ctx->grid_b, (size_t)m * sizeof(int32_t) * 2)) return rc;     // sorted idx | codes
-    if (int rc = ensure(ctx, ctx->grid_c, (size_t)(ncell + 1) * sizeof(uint32_t) * 2)) return rc;  // start | count/fill
-    if (int rc = ensure(ctx, ctx->grid_d, (size_t)(nsb + 1) * sizeof(uint32_t))) return rc;
-    gb.spts = (double *)ctx->grid_a.ptr;
-    gb.sidx = (int32_t *)ctx->grid_b.ptr;
-    uint32_t *codes = (uint32_t *)ctx->grid_b.ptr + m;
-    gb.start = (uint32_t *)ctx->grid_c.ptr;
+    if (int rc = ensure(ctx, sa, (size_t)m * (dim + 4) * sizeof(double) + 64)) return rc;   // sorted points | 32-byte records
+    if (int rc = ensure(ctx, sb, (size_t)m * sizeof(int32_t) * 2)) return rc;     // sorted idx | codes
+    if (int rc = ensure(ctx, sc, (size_t)(ncell + 1) * sizeof(uint32_t) * 2)) return rc;  // start | count/fill
+    if (int rc = ensure(ctx, sd, (size_t)(nsb + 1) * sizeof(uint32_t))) return rc;
+    gb.spts = (double *)sa.ptr;
+    gb.recs = (void *)(((uintptr_t)((double *)sa.ptr + (size_t)m * dim) + 31) & ~(uintptr_t)31);
+    gb.sidx = (int32_t *)sb.ptr;
+    uint32_t *codes = (uint32_t *)sb.ptr + m;
+    gb.start = (uint32_t *)sc.ptr;
     uint32_t *count = gb.start + (ncell + 1);
-    uint32_t *bsum = (uint32_t *)ctx->grid_d.ptr;
+    uint32_t *bsum = (uint32_t *)sd.ptr;
     const unsigned mb = (unsigned)((m + GB - 1) / GB);
     ICP_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(uint32_t), st));
     if (dim == 3) hipLaunchKernelGGL(cell_count_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, m, gp, codes, count);
@@ -394,21 +518,23 @@ int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &g
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, bsum, (int)nsb);
     hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nsb), dim3(GB), 0, st, gb.start, (const uint32_t *)bsum, ncell, (uint32_t)m);
     ICP_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(uint32_t), st));
-    if (dim == 3) hipLaunchKernelGGL(scatter_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, (const uint32_t *)codes, m, (const uint32_t *)gb.start, count, gb.spts, gb.sidx);
-    else hipLaunchKernelGGL(scatter_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, (const uint32_t *)codes, m, (const uint32_t *)gb.start, count, gb.spts, gb.sidx);
+    if (dim == 3) hipLaunchKernelGGL(scatter_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, (const uint32_t *)codes, m, (const uint32_t *)gb.start, count, gb.spts, gb.sidx, (double4 *)gb.recs);
+    else hipLaunchKernelGGL(scatter_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, (const uint32_t *)codes, m, (const uint32_t *)gb.start, count, gb.spts, gb.sidx, (double4 *)gb.recs);
     ICP_HIP_CHECK(hipGetLastError());
     gb.gp = gp;
     gb.usable = true;
     return ICP_OK;
 }
 
+long long *g_grid_dbg = nullptr;  // temporary instrumentation hook
+
 int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
                const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done) {
     const unsigned nb = (unsigned)((n + GB - 1) / GB);
     hipStream_t st = ctx->stream;
 #define ICP_GQ(D, L) \
-    hipLaunchKernelGGL((grid_query_kernel<D, L>), dim3(nb), dim3(GB), 0, st, src, n, qorder, (const double *)gb.spts, \
-                       (const int32_t *)gb.sidx, (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done)
+    hipLaunchKernelGGL((grid_query_kernel<D, L>), dim3(nb), dim3(GB), 0, st, src, n, qorder, (const double4 *)gb.recs, \
+                       (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, g_grid_dbg)
     if (gb.gp.dim == 3) {
         if (le) ICP_GQ(3, true);
         else ICP_GQ(3, false);

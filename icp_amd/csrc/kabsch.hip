@@ -10,9 +10,12 @@
 //     W = sum (nn-ct)(s-cs)^T - (1/N) sum(nn-ct) sum(s-cs)^T.
 // The 3x3 (2x2) SVD is a one-sided Jacobi iteration run by a single lane; the
 // reference applies no reflection fix (Q2) and neither does this.
+#include <vector>
+
 #include "common.h"
 
 namespace icp {
+extern long long *g_grid_dbg;
 
 constexpr int RB = 256;  // threads per reduction block
 
@@ -125,6 +128,22 @@ __global__ __launch_bounds__(RB) void reduce_partials_kernel(const double *__res
     }
 }
 
+// block-wide: red16[k] = sum_b partial[b][k] (same tree as reduce_partials_kernel); all threads sync
+__device__ __forceinline__ void block_reduce_partials(const double *__restrict__ partial, int nb, double *red16) {
+    __shared__ double red[RB / kSumSlots][kSumSlots];
+    const int tid = threadIdx.x, slot = tid & (kSumSlots - 1), g = tid / kSumSlots;
+    double v = 0.0;
+    for (int b = g; b < nb; b += RB / kSumSlots) v += partial[(int64_t)b * kSumSlots + slot];
+    red[g][slot] = v;
+    __syncthreads();
+    if (tid < kSumSlots) {
+        double r = red[0][tid];
+        for (int k = 1; k < RB / kSumSlots; ++k) r += red[k][tid];
+        red16[tid] = r;
+    }
+    __syncthreads();
+}
+
 // One-sided Jacobi SVD of a DIMxDIM matrix; returns the reference's R = (U VT)^T = V U^T.
 template <int DIM>
 __device__ void polar_rotation(const double (&W)[DIM][DIM], double (&R)[DIM][DIM]) {
@@ -144,7 +163,7 @@ __device__ void polar_rotation(const double (&W)[DIM][DIM], double (&R)[DIM][DIM
                     beta += A[r][q] * A[r][q];
                     gamma += A[r][p] * A[r][q];
                 }
-                if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+                if (gamma == 0.0 || fabs(gamma) <= 2.3e-16 * sqrt(alpha * beta)) continue;  // columns orthogonal to rounding
                 rotated = true;
                 const double zeta = (beta - alpha) / (2.0 * gamma);
                 const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -207,11 +226,34 @@ __device__ void polar_rotation(const double (&W)[DIM][DIM], double (&R)[DIM][DIM
 }
 
 template <int DIM>
+__device__ void kabsch_from_sums(const double *sums, const double *__restrict__ cs, const double *__restrict__ ct,
+                                 double *__restrict__ R_out, double *__restrict__ t_out);
+
+template <int DIM>
 __global__ void kabsch_solve_kernel(const double *__restrict__ sums, const double *__restrict__ cs,
                                     const double *__restrict__ ct, double *__restrict__ R_out,
                                     double *__restrict__ t_out, const int32_t *__restrict__ done) {
     if (done && *done) return;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    kabsch_from_sums<DIM>(sums, cs, ct, R_out, t_out);
+}
+
+// fused single-GPU form: final reduction of the block partials + solve in one launch
+template <int DIM>
+__global__ __launch_bounds__(RB) void reduce_solve_kernel(const double *__restrict__ partial, int nb,
+                                                          const double *__restrict__ cs, const double *__restrict__ ct,
+                                                          double *__restrict__ sums_out, double *__restrict__ R_out,
+                                                          double *__restrict__ t_out, const int32_t *__restrict__ done) {
+    if (done && *done) return;
+    __shared__ double tot[kSumSlots];
+    block_reduce_partials(partial, nb, tot);
+    if (threadIdx.x < kSumSlots) sums_out[threadIdx.x] = tot[threadIdx.x];
+    if (threadIdx.x == 0) kabsch_from_sums<DIM>(tot, cs, ct, R_out, t_out);
+}
+
+template <int DIM>
+__device__ void kabsch_from_sums(const double *sums, const double *__restrict__ cs, const double *__restrict__ ct,
+                                 double *__restrict__ R_out, double *__restrict__ t_out) {
     const double N = sums[15];
     double sn[DIM], ss[DIM], tbar[DIM], sbar[DIM], W[DIM][DIM], R[DIM][DIM];
     for (int c = 0; c < DIM; ++c) {
@@ -291,6 +333,13 @@ __global__ void gather_kernel(const double *__restrict__ tgt, const int32_t *__r
     for (int c = 0; c < DIM; ++c) out[i * DIM + c] = tgt[j * DIM + c];
 }
 
+// idx_out[order[i]] = idx_sorted[i]: undo the Morton ordering of the queries
+__global__ void unsort_idx_kernel(const int32_t *__restrict__ idx_sorted, const int32_t *__restrict__ order, int64_t n,
+                                  int32_t *__restrict__ idx_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx_out[order[i]] = idx_sorted[i];
+}
+
 __global__ void rigid_init_kernel(RigidState *st) {
     st->err = 100000000.0;  // icp_3d.py:105
     st->err_prev = 100000000.0;
@@ -310,6 +359,30 @@ __global__ void rigid_step_kernel(RigidState *st, double tol, int use_tol, doubl
     if (use_tol && (e - err) < tol) st->done = 1;
 }
 
+// fused: final reduction of the error partials + the end-of-iteration bookkeeping
+__global__ __launch_bounds__(RB) void reduce_step_kernel(const double *__restrict__ partial, int nb, RigidState *st,
+                                                         double tol, int use_tol, double *err_hist) {
+    if (st->done) return;
+    __shared__ double red[RB];
+    const int tid = threadIdx.x;
+    double v = 0.0;
+    for (int b = tid; b < nb; b += RB) v += partial[(int64_t)b * kSumSlots];
+    red[tid] = v;
+    __syncthreads();
+    for (int o = RB / 2; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double e = st->err_prev, err = red[0];
+        st->err = err;
+        st->err_prev = err;
+        if (err_hist) err_hist[st->iters] = err;
+        st->iters += 1;
+        if (use_tol && (e - err) < tol) st->done = 1;
+    }
+}
+
 // icp_3d.py:118-121
 __global__ void rigid_finish_kernel(const RigidState *st, int dim, double *T, int32_t *iters_out) {
     const int d1 = dim + 1;
@@ -324,7 +397,7 @@ __global__ void rigid_finish_kernel(const RigidState *st, int dim, double *T, in
 
 static inline int nblocks_for(int64_t n) {
     int64_t nb = (n + RB - 1) / RB;
-    if (nb > kMaxPartials) nb = kMaxPartials;
+    if (nb > 512) nb = 512;  // 2 blocks per CU; the final single-block reduce stays short
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -337,7 +410,7 @@ static int reduce_to(icp_ctx *ctx, int nb, double *out_dev, int nout, int mean_s
 }
 
 static int shard_sums(icp_ctx *ctx, const double *src, const double *tgt, const int32_t *idx, int64_t n, int dim,
-                      const double *cs, const double *ct, double *sums_out, const int32_t *done) {
+                      const double *cs, const double *ct, double *sums_out, const int32_t *done, int *nb_out = nullptr) {
     if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
     const int nb = nblocks_for(n);
     double *part = (double *)ctx->partials.ptr;
@@ -350,6 +423,10 @@ static int shard_sums(icp_ctx *ctx, const double *src, const double *tgt, const 
         else hipLaunchKernelGGL((shard_sums_kernel<2, false>), dim3(nb), dim3(RB), 0, st, src, tgt, idx, n, cs, ct, part, done);
     }
     ICP_HIP_CHECK(hipGetLastError());
+    if (nb_out) {  // caller reduces the partial rows itself (fused kernels)
+        *nb_out = nb;
+        return ICP_OK;
+    }
     return reduce_to(ctx, nb, sums_out, kSumSlots, 0, done);
 }
 
@@ -373,7 +450,8 @@ static int kabsch_solve(icp_ctx *ctx, const double *sums, int dim, const double 
 
 // mode 0 apply, 1 apply+err(gather), 2 distance
 static int apply_err(icp_ctx *ctx, int mode, const double *src, const double *tgt, const int32_t *idx, int64_t n,
-                     int dim, const double *R, const double *t, double *ss_out, double *err_out, const int32_t *done) {
+                     int dim, const double *R, const double *t, double *ss_out, double *err_out, const int32_t *done,
+                     int *nb_out = nullptr) {
     if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
     const int nb = nblocks_for(n);
     double *part = (double *)ctx->partials.ptr;
@@ -392,6 +470,10 @@ static int apply_err(icp_ctx *ctx, int mode, const double *src, const double *tg
 #undef ICP_LAUNCH_AE
     ICP_HIP_CHECK(hipGetLastError());
     if (mode == 0) return ICP_OK;
+    if (nb_out) {
+        *nb_out = nb;
+        return ICP_OK;
+    }
     // only slot 0 of each partial row is written in this mode
     return reduce_to(ctx, nb, err_out, 1, 0, done);
 }
@@ -492,8 +574,25 @@ extern "C" int icp_rigid_run(icp_ctx *ctx, const double *src, int64_t n, const d
     ICP_REQUIRE(max_iter > 0, "run = 0 leaves R undefined (icp_3d.py:118-120)");
     if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
     if (int rc = ensure(ctx, ctx->work_c, (size_t)n * dim * sizeof(double))) return rc;
+    // the target never changes inside the loop: build its search grid once
+    GridBuild grid, qsort;
+    if (grid_worthwhile(n, m, flags))
+        if (int rc = grid_build(ctx, tgt, m, dim, grid)) return rc;
+    if (!grid.usable) flags |= ICP_FORCE_BRUTE;
+    // With the grid, put the source into Morton order once: lanes of a wave then search the same
+    // few cells, and a rigid motion keeps neighbours neighbours, so the order stays good for
+    // every iteration.  Reductions run over the sorted copy (any order is a valid sum order);
+    // only the user-visible correspondences are scattered back to the caller's order.
+    const int32_t *order = nullptr;
+    if (grid.usable && n >= 32768) {
+        if (int rc = grid_build(ctx, src, n, dim, qsort, 1)) return rc;
+        if (qsort.usable) {
+            src = qsort.spts;
+            order = qsort.sidx;
+        }
+    }
     int32_t *idx = idx_out;
-    if (!idx) {
+    if (!idx || order) {
         if (int rc = ensure(ctx, ctx->work_d, (size_t)n * sizeof(int32_t))) return rc;
         idx = (int32_t *)ctx->work_d.ptr;
     }
@@ -507,20 +606,70 @@ extern "C" int icp_rigid_run(icp_ctx *ctx, const double *src, int64_t n, const d
     if (int rc = column_sums(ctx, tgt, m, dim, st->ct, 1)) return rc;
     ICP_HIP_CHECK(hipMemcpyAsync(ss, src, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToDevice, s));  // icp_3d.py:104
     const int32_t *done = &st->done;
-    // the target never changes inside the loop: build its search grid once
-    GridBuild grid;
-    if (grid_worthwhile(n, m, flags))
-        if (int rc = grid_build(ctx, tgt, m, dim, grid)) return rc;
-    if (!grid.usable) flags |= ICP_FORCE_BRUTE;
     for (int it = 0; it < max_iter; ++it) {
         if (int rc = closest_dispatch(ctx, ss, n, tgt, m, dim, flags, idx, nullptr, done, &grid)) return rc;
-        if (int rc = shard_sums(ctx, src, tgt, idx, n, dim, st->cs, st->ct, st->sums, done)) return rc;
-        if (int rc = kabsch_solve(ctx, st->sums, dim, st->cs, st->ct, st->R, st->t, done)) return rc;
-        if (int rc = apply_err(ctx, 1, src, tgt, idx, n, dim, st->R, st->t, ss, st->sums, done)) return rc;
-        hipLaunchKernelGGL(rigid_step_kernel, dim3(1), dim3(1), 0, s, st, tol, use_tol, err_hist_dev);
+        int nb = 0;
+        const double *part = (const double *)ctx->partials.ptr;
+        if (int rc = shard_sums(ctx, src, tgt, idx, n, dim, st->cs, st->ct, st->sums, done, &nb)) return rc;
+        part = (const double *)ctx->partials.ptr;
+        if (dim == 3) hipLaunchKernelGGL(reduce_solve_kernel<3>, dim3(1), dim3(RB), 0, s, part, nb, (const double *)st->cs, (const double *)st->ct, st->sums, st->R, st->t, done);
+        else hipLaunchKernelGGL(reduce_solve_kernel<2>, dim3(1), dim3(RB), 0, s, part, nb, (const double *)st->cs, (const double *)st->ct, st->sums, st->R, st->t, done);
+        if (int rc = apply_err(ctx, 1, src, tgt, idx, n, dim, st->R, st->t, ss, st->sums, done, &nb)) return rc;
+        hipLaunchKernelGGL(reduce_step_kernel, dim3(1), dim3(RB), 0, s, part, nb, st, tol, use_tol, err_hist_dev);
         ICP_HIP_CHECK(hipGetLastError());
     }
+    if (order && idx_out)
+        hipLaunchKernelGGL(unsort_idx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int32_t *)idx, order, n, idx_out);
     hipLaunchKernelGGL(rigid_finish_kernel, dim3(1), dim3(1), 0, s, (const RigidState *)st, dim, T_out_dev, iters_out_dev);
     ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+extern "C" int icp_bench_grid_query(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
+                                    int reps, double *ms_out_dev) {
+    ICP_COMMON_ARGS(ctx, dim);
+    ICP_REQUIRE(src && tgt && ms_out_dev && n > 0 && m > 0 && reps > 0, "bad argument");
+    GridBuild grid, qsort;
+    if (int rc = grid_build(ctx, tgt, m, dim, grid)) return rc;
+    if (!grid.usable) {
+        set_error("icp_bench_grid_query: target has non-finite coordinates");
+        return ICP_ERR_UNSUPPORTED;
+    }
+    if (int rc = grid_build(ctx, src, n, dim, qsort, 1)) return rc;
+    const double *q = qsort.usable ? qsort.spts : src;
+    if (int rc = ensure(ctx, ctx->work_d, (size_t)n * sizeof(int32_t))) return rc;
+    int32_t *idx = (int32_t *)ctx->work_d.ptr;
+    hipStream_t s = ctx->stream;
+    if (int rc = grid_query(ctx, grid, q, n, nullptr, false, nullptr, idx, nullptr, nullptr)) return rc;  // warm
+    hipEvent_t e0, e1;
+    ICP_HIP_CHECK(hipEventCreate(&e0));
+    ICP_HIP_CHECK(hipEventCreate(&e1));
+    ICP_HIP_CHECK(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r)
+        if (int rc = grid_query(ctx, grid, q, n, nullptr, false, nullptr, idx, nullptr, nullptr)) return rc;
+    ICP_HIP_CHECK(hipEventRecord(e1, s));
+    ICP_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    ICP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (const char *dpath = getenv("ICP_GRID_DEBUG")) {
+        long long *d = nullptr;
+        ICP_HIP_CHECK(hipMalloc((void **)&d, (size_t)n * 3 * sizeof(long long)));
+        g_grid_dbg = d;
+        int rc = grid_query(ctx, grid, q, n, nullptr, false, nullptr, idx, nullptr, nullptr);
+        g_grid_dbg = nullptr;
+        if (rc) return rc;
+        std::vector<long long> h((size_t)n * 3);
+        ICP_HIP_CHECK(hipMemcpy(h.data(), d, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        if (FILE *f = fopen(dpath, "wb")) {
+            fwrite(h.data(), sizeof(long long), h.size(), f);
+            fclose(f);
+        }
+    }
+    const double avg = (double)ms / reps;
+    ICP_HIP_CHECK(hipMemcpyAsync(ms_out_dev, &avg, sizeof(double), hipMemcpyHostToDevice, s));
+    ICP_HIP_CHECK(hipStreamSynchronize(s));
     return ICP_OK;
 }

@@ -44,9 +44,36 @@ class GpuOps:
         self.ctx.call("icp_column_sums", ptr(a), a.shape[0], a.shape[1], ptr(out))
         return out
 
+    def prepare(self, src, tgt):
+        """Once per run: search index over the (replicated, fixed) target and a Morton-ordered
+        copy of the local source shard (sums are order-independent; a rigid motion keeps the
+        order spatially coherent).  Returns the source array the iterations should use."""
+        import ctypes
+        self._tgt_keepalive = tgt
+        h = ctypes.c_void_p()
+        self.ctx.call("icp_target_create", ptr(tgt), tgt.shape[0], tgt.shape[1], ctypes.byref(h))
+        self._target = h
+        if src.shape[0] >= 32768 and bool(self.torch.isfinite(src).all()):
+            out = self.torch.empty_like(src)
+            order = self.new_idx(src.shape[0])
+            self.ctx.call("icp_morton_sort", ptr(src), src.shape[0], src.shape[1], ptr(out), ptr(order))
+            return out
+        return src
+
     def closest(self, ss, tgt, idx):
-        self.ctx.call("icp_closest", ptr(ss), ss.shape[0], ptr(tgt), tgt.shape[0], ss.shape[1], self.flags, ptr(idx),
-                      ptr(None))
+        if getattr(self, "_target", None) is not None:
+            self.ctx.call("icp_closest_target", self._target, ptr(ss), ss.shape[0], self.flags, ptr(idx), ptr(None))
+        else:
+            self.ctx.call("icp_closest", ptr(ss), ss.shape[0], ptr(tgt), tgt.shape[0], ss.shape[1], self.flags,
+                          ptr(idx), ptr(None))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_target", None) is not None:
+                self.ctx.lib.icp_target_destroy(self.ctx.handle, self._target)
+                self._target = None
+        except Exception:
+            pass
 
     def new_idx(self, n):
         return self.torch.empty(n, dtype=self.torch.int32, device="cuda:%d" % self.ctx.device)
@@ -86,6 +113,8 @@ class ShardedICP:
         self.ops, self.comm = ops, comm
         self.src = ops.to_dev(src_shard)
         self.tgt = ops.to_dev(tgt)
+        if hasattr(ops, "prepare"):
+            self.src = ops.prepare(self.src, self.tgt)
         self.dim = self.src.shape[1]
         n_loc = self.src.shape[0]
         # iteration-invariant shifts: global mean of the ORIGINAL source (Q1) and target mean

@@ -76,6 +76,22 @@ int icp_memcpy_d2h(icp_ctx *ctx, void *dst_host, const void *src_dev, size_t byt
 int icp_closest(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
                 unsigned flags, int32_t *idx_out, double *d2_out);
 
+/* Persistent search index over one target cloud, for callers that run many Match passes
+ * against the same target (every ICP iteration does: the `target` argument of icp_3d.py:102
+ * never changes inside the loop).  create builds the grid once (synchronises);
+ * icp_closest_target then never rebuilds and never synchronises.  The target buffer must stay
+ * alive and unchanged while the handle exists.  Results are identical to icp_closest. */
+typedef struct icp_target icp_target;
+int icp_target_create(icp_ctx *ctx, const double *tgt, int64_t m, int dim, icp_target **out);
+int icp_target_destroy(icp_ctx *ctx, icp_target *t);
+int icp_closest_target(icp_ctx *ctx, const icp_target *t, const double *src, int64_t n, unsigned flags,
+                       int32_t *idx_out, double *d2_out);
+
+/* Morton (Z-curve) ordering of a point set: sorted_out[i] = pts[order_out[i]].  Used to put a
+ * source shard into a cache-friendly order once per run (a rigid motion keeps neighbours
+ * neighbours).  No counterpart in the reference.  Synchronises. */
+int icp_morton_sort(icp_ctx *ctx, const double *pts, int64_t n, int dim, double *sorted_out, int32_t *order_out);
+
 /* nn[i] = tgt[idx[i]]: the gather inside Match, icp_3d.py:52, nicp3d.cpp:266 */
 int icp_gather_points(icp_ctx *ctx, const double *tgt, const int32_t *idx, int64_t n, int dim,
                       double *nn_out);
@@ -124,6 +140,13 @@ int icp_shard_apply_err(icp_ctx *ctx, const double *src, const double *tgt, cons
                         double *err_out_dev);
 /* column sums of a [n,dim] array -> out_dev[dim] (for the shifts above) */
 int icp_column_sums(icp_ctx *ctx, const double *a, int64_t n, int dim, double *out_dev);
+
+/* Measurement hook (no counterpart in the reference): builds the target grid and the Morton
+ * order of the queries exactly as icp_rigid_run does, then times `reps` launches of the grid
+ * search kernel alone with HIP events on the context's stream; ms_out_dev[0] = average
+ * milliseconds per launch.  Synchronises. */
+int icp_bench_grid_query(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
+                         int reps, double *ms_out_dev);
 
 /* ------------------------------------------------------------ non-rigid ICP */
 

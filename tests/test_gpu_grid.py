@@ -89,4 +89,45 @@ def test_grid_inside_icp(rigid):
     b = rigid.rigid_icp(src, tgt, 0.10, 50, want_idx=True, force_brute=True)
     assert int(a["iters"].cpu()[0]) == int(b["iters"].cpu()[0])
     assert np.array_equal(a["idx"].cpu().numpy(), b["idx"].cpu().numpy())
-    assert np.array_equal(a["T"].cpu().numpy(), b["T"].cpu().numpy())     # identical indices -> identical sums
+    # identical correspondences; the sums run over the Morton-ordered source in the grid path
+    np.testing.assert_allclose(a["T"].cpu().numpy(), b["T"].cpu().numpy(), rtol=1e-12, atol=1e-13)
+
+
+def test_target_handle_and_morton_sort(rigid):
+    import ctypes
+    import torch
+    from icp_amd._lib import get_context, ptr
+    ctx = get_context()
+    rng = np.random.default_rng(31)
+    tgt = ctx.to_dev(rng.standard_normal((50000, 3)))
+    src = ctx.to_dev(rng.standard_normal((40000, 3)) * 1.2)
+    h = ctypes.c_void_p()
+    ctx.call("icp_target_create", ptr(tgt), tgt.shape[0], 3, ctypes.byref(h))
+    idx = ctx.empty((src.shape[0],), torch.int32)
+    d2 = ctx.empty((src.shape[0],))
+    for _ in range(2):
+        ctx.call("icp_closest_target", h, ptr(src), src.shape[0], 0, ptr(idx), ptr(d2))
+    oi, od = c_oracle.match_idx(src.cpu().numpy(), tgt.cpu().numpy())
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(d2.cpu().numpy(), od)
+    ctx.call("icp_closest_target", h, ptr(src), 100, 1, ptr(idx), ptr(None))       # compare-sqrt through the handle
+    oi2, _ = c_oracle.match_idx(src.cpu().numpy()[:100], tgt.cpu().numpy(), compare_sqrt=True)
+    assert np.array_equal(idx.cpu().numpy()[:100], oi2)
+    ctx.lib.icp_target_destroy(ctx.handle, h)
+    out = torch.empty_like(src)
+    order = ctx.empty((src.shape[0],), torch.int32)
+    ctx.call("icp_morton_sort", ptr(src), src.shape[0], 3, ptr(out), ptr(order))
+    o = order.cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(src.shape[0]))                    # a permutation
+    assert np.array_equal(out.cpu().numpy(), src.cpu().numpy()[o])
+
+
+def test_sharded_ops_single_process(rigid):
+    """icp_amd.dist with the real GpuOps (no collective): same answer as the fused loop / oracle."""
+    from icp_amd.dist import Comm, GpuOps, sharded_icp
+    src, tgt = orc.make_rigid_cloud(40000, seed=14)
+    T, hist = sharded_icp(GpuOps(), Comm(enabled=False), src, tgt, 0.10, 50)
+    r = rigid.rigid_icp(src, tgt, 0.10, 50)
+    n = int(r["iters"].cpu()[0])
+    assert len(hist) == n
+    np.testing.assert_allclose(T, r["T"].cpu().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(hist, r["err_hist"].cpu().numpy()[:n], rtol=1e-9, atol=1e-9)
