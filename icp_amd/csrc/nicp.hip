@@ -20,6 +20,7 @@
 //   Q7 (2-D) b-columns of the fit block carry no weight factor.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -500,18 +501,24 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
                 else gb[c] += end == 0 ? c_smooth * (u0 - u1) : c_smooth * (u1 - u0);
             }
         }
+        double pap = 0.0;
 #pragma unroll
         for (int r = 0; r < DIM; ++r)
 #pragma unroll
             for (int c = 0; c < DIM; ++c) {
                 const int64_t o = j * S + r * DIM + c;
-                out[o] = gA[r][c] + (lam_d2 ? lam * lam_d2[o] * p_in[o] : 0.0);
+                const double val = gA[r][c] + (lam_d2 ? lam * lam_d2[o] * p_in[o] : 0.0);
+                out[o] = val;
+                if (lam_d2) pap += val * p_in[o];
             }
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
             const int64_t o = j * S + DIM * DIM + c;
-            out[o] = gb[c] + (lam_d2 ? lam * lam_d2[o] * p_in[o] : 0.0);
+            const double val = gb[c] + (lam_d2 ? lam * lam_d2[o] * p_in[o] : 0.0);
+            out[o] = val;
+            if (lam_d2) pap += val * p_in[o];
         }
+        gacc[8] = pap;  // vertex part of p . (A p), summed by the tail kernels
         // global columns: vertex j as fit row j
         for (int an = 0; an < NANG; ++an) {
             double a = 0.0;
@@ -527,16 +534,17 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
 #pragma unroll
         for (int o = 0; o < DIM; ++o) gacc[NANG + o] = SQUARE ? c_fit * c_fit : -c_fit * u[j * DIM + o];
     }
-    // block partial of the NG global entries (reduced by tail_kernel)
-    __shared__ double red[NB / 64][NG];
+    // block partial of the NG global entries + p.Ap (reduced by tail_kernel / cg_tail_alpha_kernel)
+    __shared__ double red[NB / 64][9];
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < NG; ++k) {
+    for (int k = 0; k < 9; ++k) {
+        if (k >= NG && k != 8) continue;
         const double s = wave_sum(gacc[k]);
         if ((tid & 63) == 0) red[tid >> 6][k] = s;
     }
     __syncthreads();
-    if (tid < NG) {
+    if (tid < 9 && (tid < NG || tid == 8)) {
         double s = red[0][tid];
         for (int w = 1; w < NB / 64; ++w) s += red[w][tid];
         partial[(int64_t)blockIdx.x * kSumSlots + tid] = s;
@@ -665,6 +673,428 @@ __global__ __launch_bounds__(NB) void scaling_kernel(const double *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------ two-level preconditioner
+// M^-1 = blockdiag(J^T J + lam D^2)^-1  +  Z (Z^T (J^T J + lam D^2) Z)^-1 Z^T.
+// The per-vertex S x S blocks remove the 1e6 : 1e4 : 1e-2 spread between the rigidity,
+// smoothness and fit terms inside one vertex; the coarse space Z removes the modes the
+// stiffness terms cannot see at all: a common rotation / translation of every vertex
+// (A_j -> A_j Q, b_j -> (v_j + b_j) Q - v_j + t leaves E_rigid and E_smooth unchanged) together
+// with the explicit global parameters that duplicate them (the gauge of this model).  Without
+// it CG needs ~1e4 iterations per step at 10k vertices.
+constexpr int NZMAX = 12;
+struct Coarse {
+    double Einv[NZMAX * NZMAX];
+    double E[NZMAX * NZMAX];
+    double ztr[NZMAX], y[NZMAX];
+    double tail_minv[6];
+};
+
+// the NG per-vertex zero-stiffness modes at vertex j: z[k][0..S)
+template <int DIM>
+__device__ __forceinline__ void zmodes(const double *__restrict__ Pj, const double *__restrict__ vj,
+                                       double (&z)[Lay<DIM>::NG][Lay<DIM>::S]) {
+    constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
+#pragma unroll
+    for (int k = 0; k < NG; ++k)
+#pragma unroll
+        for (int e = 0; e < S; ++e) z[k][e] = 0.0;
+    if (DIM == 3) {
+        // x Omega_0 = (-x1, x0, 0); x Omega_1 = (0, -x2, x1); x Omega_2 = (x2, 0, -x0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // rows of A, then the row vector v_j + b_j
+            double x0, x1, x2;
+            if (r < 3) { x0 = Pj[r * 3]; x1 = Pj[r * 3 + 1]; x2 = Pj[r * 3 + 2]; }
+            else { x0 = vj[0] + Pj[9]; x1 = vj[1] + Pj[10]; x2 = vj[2] + Pj[11]; }
+            const int o = r * 3;
+            z[0][o] = -x1; z[0][o + 1] = x0;
+            z[1][o + 1] = -x2; z[1][o + 2] = x1;
+            z[2][o] = x2; z[2][o + 2] = -x0;
+        }
+        z[3][9] = 1.0; z[4][10] = 1.0; z[5][11] = 1.0;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double x0, x1;
+            if (r < 2) { x0 = Pj[r * 2]; x1 = Pj[r * 2 + 1]; }
+            else { x0 = vj[0] + Pj[4]; x1 = vj[1] + Pj[5]; }
+            z[0][r * 2] = -x1; z[0][r * 2 + 1] = x0;
+        }
+        z[1][4] = 1.0; z[2][5] = 1.0;
+    }
+}
+
+// S x S diagonal block of J^T J + lam D^2 for every vertex, inverted; packed lower triangle
+template <int DIM, bool COMPAT>
+__global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict__ P, const double *__restrict__ wt, int K,
+                                                       const double *__restrict__ v, const int32_t *__restrict__ edges,
+                                                       const int32_t *__restrict__ rev_ptr, const int32_t *__restrict__ rev_ent,
+                                                       const int32_t *__restrict__ inc_ptr, const int32_t *__restrict__ inc_ent,
+                                                       int64_t n, const Globals *__restrict__ g, double c_fit, double c_rigid,
+                                                       double c_smooth, const double *__restrict__ col2,
+                                                       const double *__restrict__ d2, double lam,
+                                                       double *__restrict__ binv, Coarse *__restrict__ coarse) {
+    constexpr int S = Lay<DIM>::S, NA = Lay<DIM>::NA, NG = Lay<DIM>::NG, TRI = S * (S + 1) / 2;
+    const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (j == 0)
+        for (int k = 0; k < NG; ++k) coarse->tail_minv[k] = 1.0 / (col2[n * S + k] + lam * d2[n * S + k]);
+    if (j >= n) return;
+    double B[S][S];
+    for (int a = 0; a < S; ++a)
+        for (int b = 0; b < S; ++b) B[a][b] = 0.0;
+    double M[DIM][DIM];  // R R^T
+    for (int a = 0; a < DIM; ++a)
+        for (int b = 0; b < DIM; ++b) {
+            double m = 0.0;
+            for (int o = 0; o < DIM; ++o) m += g->R[a * DIM + o] * g->R[b * DIM + o];
+            M[a][b] = m;
+        }
+    double vj[DIM];
+    for (int a = 0; a < DIM; ++a) vj[a] = v[j * DIM + a];
+    // fit rows that reference vertex j: entries -c_fit w d[r] R[c][o] (A) and -c_fit wb R[c][o] (b)
+    for (int32_t e = rev_ptr[j]; e < rev_ptr[j + 1]; ++e) {
+        const int32_t ent = rev_ent[e];
+        const int64_t i = ent / K;
+        const double w = wt[ent];
+        if (w == 0.0) continue;
+        const double wb = (DIM == 2 && COMPAT) ? 1.0 : w;
+        double u[S];  // the row pattern up to the R factor: u[r*DIM+c] = w d[r], u[NA+c] = wb (for column c)
+        double d[DIM];
+        for (int a = 0; a < DIM; ++a) d[a] = v[i * DIM + a] - vj[a];
+        const double cf2 = c_fit * c_fit;
+        for (int r = 0; r < DIM; ++r)
+            for (int c = 0; c < DIM; ++c) {
+                for (int r2 = 0; r2 < DIM; ++r2)
+                    for (int c2 = 0; c2 < DIM; ++c2) B[r * DIM + c][r2 * DIM + c2] += cf2 * w * w * d[r] * d[r2] * M[c][c2];
+                for (int c2 = 0; c2 < DIM; ++c2) {
+                    const double t = cf2 * w * wb * d[r] * M[c][c2];
+                    B[r * DIM + c][NA + c2] += t;
+                    B[NA + c2][r * DIM + c] += t;
+                }
+            }
+        for (int c = 0; c < DIM; ++c)
+            for (int c2 = 0; c2 < DIM; ++c2) B[NA + c][NA + c2] += cf2 * wb * wb * M[c][c2];
+        (void)u;
+    }
+    // rigid rows: gradients of the NRIG terms w.r.t. the NA entries of A_j
+    {
+        const double *A = P + j * S;
+        const double cr2 = c_rigid * c_rigid;
+        constexpr int NRIG = Lay<DIM>::NRIG;
+        double G[NRIG][NA];
+        for (int m = 0; m < NRIG; ++m)
+            for (int e = 0; e < NA; ++e) G[m][e] = 0.0;
+        if (DIM == 3) {
+            for (int c = 0; c < 3; ++c) {
+                const double a0 = A[c], a1 = A[3 + c], a2 = A[6 + c];
+                G[0][c] = a1; G[0][3 + c] = a0;
+                G[1][3 + c] = a2; G[1][6 + c] = a1;
+                G[2][c] = a2; G[2][6 + c] = a0;
+                G[3][c] = -2 * a0; G[4][3 + c] = -2 * a1; G[5][6 + c] = -2 * a2;
+            }
+        } else {
+            for (int c = 0; c < 2; ++c) {
+                const double a0 = A[c], a1 = A[2 + c];
+                G[0][c] = a1; G[0][2 + c] = a0;
+                G[1][c] = -2 * a0; G[2][2 + c] = -2 * a1;
+            }
+        }
+        for (int m = 0; m < NRIG; ++m)
+            for (int a = 0; a < NA; ++a)
+                for (int b = 0; b < NA; ++b) B[a][b] += cr2 * G[m][a] * G[m][b];
+    }
+    // smooth rows of the incident edges
+    for (int32_t e = inc_ptr[j]; e < inc_ptr[j + 1]; ++e) {
+        const int32_t ent = inc_ent[e];
+        const int64_t ed = ent >> 1;
+        const double sgn = (ent & 1) ? -1.0 : 1.0;
+        const int64_t p1 = edges[ed * 2], p2 = edges[ed * 2 + 1];
+        const double cs2 = c_smooth * c_smooth;
+        double d[DIM];
+        for (int a = 0; a < DIM; ++a) d[a] = v[p2 * DIM + a] - v[p1 * DIM + a];
+        for (int c = 0; c < DIM; ++c) {
+            for (int r = 0; r < DIM; ++r) {
+                for (int r2 = 0; r2 < DIM; ++r2) B[r * DIM + c][r2 * DIM + c] += cs2 * d[r] * d[r2];
+                B[r * DIM + c][NA + c] += sgn * cs2 * d[r];
+                B[NA + c][r * DIM + c] += sgn * cs2 * d[r];
+            }
+            B[NA + c][NA + c] += 2 * cs2;
+        }
+    }
+    for (int a = 0; a < S; ++a) B[a][a] += lam * d2[j * S + a];
+    // Cholesky B = L L^T, Linv, Binv = Linv^T Linv; on breakdown fall back to the diagonal
+    double L[S][S];
+    bool ok = true;
+    for (int a = 0; a < S; ++a)
+        for (int b = 0; b <= a; ++b) {
+            double sum = B[a][b];
+            for (int k = 0; k < b; ++k) sum -= L[a][k] * L[b][k];
+            if (a == b) {
+                if (!(sum > 0.0)) ok = false;
+                L[a][a] = ok ? sqrt(sum) : 1.0;
+            } else {
+                L[a][b] = sum / L[b][b];
+            }
+        }
+    double *out = binv + j * TRI;
+    if (!ok) {
+        int q = 0;
+        for (int a = 0; a < S; ++a)
+            for (int b = 0; b <= a; ++b) out[q++] = a == b ? 1.0 / B[a][a] : 0.0;
+        return;
+    }
+    double Li[S][S];  // inverse of L (lower)
+    for (int a = 0; a < S; ++a)
+        for (int b = 0; b < S; ++b) Li[a][b] = 0.0;
+    for (int c = 0; c < S; ++c) {
+        Li[c][c] = 1.0 / L[c][c];
+        for (int a = c + 1; a < S; ++a) {
+            double sum = 0.0;
+            for (int k = c; k < a; ++k) sum -= L[a][k] * Li[k][c];
+            Li[a][c] = sum / L[a][a];
+        }
+    }
+    int q = 0;
+    for (int a = 0; a < S; ++a)
+        for (int b = 0; b <= a; ++b) {
+            double sum = 0.0;
+            for (int k = a; k < S; ++k) sum += Li[k][a] * Li[k][b];
+            out[q++] = sum;
+        }
+}
+
+// column a of Z as a full parameter vector
+template <int DIM>
+__global__ __launch_bounds__(NB) void zcol_kernel(const double *__restrict__ P, const double *__restrict__ v, int64_t n,
+                                                 int a, double *__restrict__ out) {
+    constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
+    const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
+    if (j < n) {
+        double z[NG][S];
+        zmodes<DIM>(P + j * S, v + j * DIM, z);
+        for (int e = 0; e < S; ++e) {
+            double val = 0.0;
+            for (int k = 0; k < NG; ++k) val = (k == a) ? z[k][e] : val;
+            out[j * S + e] = val;
+        }
+    } else if (j < n + NG) {
+        out[n * S + (j - n)] = (a - NG == (int)(j - n)) ? 1.0 : 0.0;
+    }
+}
+
+// partial[b][k] = sum over the block's vertices of z_k(j) . r_j  (k < NG)
+template <int DIM>
+__global__ __launch_bounds__(NB) void zt_kernel(const double *__restrict__ P, const double *__restrict__ v, int64_t n,
+                                               const double *__restrict__ r, double *__restrict__ partial) {
+    constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
+    const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
+    double acc[NG];
+    for (int k = 0; k < NG; ++k) acc[k] = 0.0;
+    if (j < n) {
+        double z[NG][S];
+        zmodes<DIM>(P + j * S, v + j * DIM, z);
+        for (int k = 0; k < NG; ++k)
+            for (int e = 0; e < S; ++e) acc[k] += z[k][e] * r[j * S + e];
+    }
+    __shared__ double red[NB / 64][NG];
+    const int tid = threadIdx.x;
+    for (int k = 0; k < NG; ++k) {
+        const double s = wave_sum(acc[k]);
+        if ((tid & 63) == 0) red[tid >> 6][k] = s;
+    }
+    __syncthreads();
+    if (tid < NG) {
+        double s = red[0][tid];
+        for (int w = 1; w < NB / 64; ++w) s += red[w][tid];
+        partial[(int64_t)blockIdx.x * kSumSlots + tid] = s;
+    }
+}
+// E[:, a] = [sum_b partial[b][0..NG) | w_tail[0..NG)]   (single block)
+__global__ void ecol_kernel(const double *__restrict__ partial, int nb, int ng, const double *__restrict__ w_tail, int a,
+                            Coarse *__restrict__ coarse) {
+    __shared__ double red[NB];
+    const int tid = threadIdx.x;
+    const int nz = 2 * ng;
+    for (int k = 0; k < ng; ++k) {
+        double s = 0.0;
+        for (int b = tid; b < nb; b += NB) s += partial[(int64_t)b * kSumSlots + k];
+        red[tid] = s;
+        __syncthreads();
+        for (int o = NB / 2; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            coarse->E[k * nz + a] = red[0];
+            coarse->E[(ng + k) * nz + a] = w_tail[k];
+        }
+        __syncthreads();
+    }
+}
+
+// tot[k] = sum_b partial[b][k] for the slots listed in `mask`; one wave per slot (blockDim = 64 * 16)
+__device__ __forceinline__ void rows_sum_16(const double *__restrict__ partial, int nb, unsigned mask, double *tot) {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (k < kSumSlots && ((mask >> k) & 1u)) {
+        double a = 0.0;
+        for (int b = lane; b < nb; b += 64) a += partial[(int64_t)b * kSumSlots + k];
+        a = wave_sum(a);
+        if (lane == 0) tot[k] = a;
+    }
+    __syncthreads();
+}
+
+// after J^T: finish the tail of A p, p.Ap and alpha  (single block)
+__global__ __launch_bounds__(1024) void cg_tail_alpha_kernel(const double *__restrict__ partial, int nb, int ng,
+                                                             const double *__restrict__ d2_tail,
+                                                             const double *__restrict__ p_tail, double lam,
+                                                             double *__restrict__ Ap_tail, Scal *__restrict__ s) {
+    __shared__ double tot[kSumSlots];
+    const int tid = threadIdx.x;
+    rows_sum_16(partial, nb, ((1u << ng) - 1u) | (1u << 8), tot);
+    if (tid == 0 && !s->stop) {
+        double pap = tot[8];
+        for (int k = 0; k < ng; ++k) {
+            const double val = tot[k] + lam * d2_tail[k] * p_tail[k];
+            Ap_tail[k] = val;
+            pap += val * p_tail[k];
+        }
+        s->pAp = pap;
+        s->alpha = pap > 0 ? s->rz / pap : 0.0;
+        if (!(pap > 0)) s->stop = 2;  // breakdown (non-positive curvature / NaN)
+    }
+}
+
+// x += alpha p; r -= alpha Ap; zb = Binv r (per vertex); partials: r.zb, r.r, Z^T r
+template <int DIM>
+__global__ __launch_bounds__(NB) void cg_update_prec_kernel(const Scal *__restrict__ s, const double *__restrict__ P,
+                                                           const double *__restrict__ v, int64_t n,
+                                                           double *__restrict__ x, double *__restrict__ r,
+                                                           double *__restrict__ zb, const double *__restrict__ p,
+                                                           const double *__restrict__ Ap, const double *__restrict__ binv,
+                                                           double *__restrict__ partial) {
+    constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG, TRI = S * (S + 1) / 2;
+    const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
+    double acc[2 + NG];
+    for (int k = 0; k < 2 + NG; ++k) acc[k] = 0.0;
+    if (j < n && !s->stop) {
+        const double alpha = s->alpha;
+        double rj[S], zj[S];
+        for (int e = 0; e < S; ++e) {
+            x[j * S + e] += alpha * p[j * S + e];
+            rj[e] = r[j * S + e] - alpha * Ap[j * S + e];
+            r[j * S + e] = rj[e];
+            zj[e] = 0.0;
+        }
+        const double *B = binv + j * TRI;
+        int q = 0;
+        for (int a = 0; a < S; ++a)
+            for (int b = 0; b <= a; ++b) {
+                const double m = B[q++];
+                zj[a] += m * rj[b];
+                if (a != b) zj[b] += m * rj[a];
+            }
+        double z[NG][S];
+        zmodes<DIM>(P + j * S, v + j * DIM, z);
+        for (int e = 0; e < S; ++e) {
+            zb[j * S + e] = zj[e];
+            acc[0] += rj[e] * zj[e];
+            acc[1] += rj[e] * rj[e];
+            for (int k = 0; k < NG; ++k) acc[2 + k] += z[k][e] * rj[e];
+        }
+    }
+    __shared__ double red[NB / 64][2 + NG];
+    const int tid = threadIdx.x;
+    for (int k = 0; k < 2 + NG; ++k) {
+        const double t = wave_sum(acc[k]);
+        if ((tid & 63) == 0) red[tid >> 6][k] = t;
+    }
+    __syncthreads();
+    if (tid < 2 + NG) {
+        double t = red[0][tid];
+        for (int w = 1; w < NB / 64; ++w) t += red[w][tid];
+        partial[(int64_t)blockIdx.x * kSumSlots + tid] = t;
+    }
+}
+
+// single block: tail update, coarse solve y = Einv Z^T r, r.z, beta, stop test
+__global__ __launch_bounds__(1024) void cg_coarse_kernel(const double *__restrict__ partial, int nb, int ng,
+                                                         double *__restrict__ x_tail, double *__restrict__ r_tail,
+                                                         double *__restrict__ zb_tail, const double *__restrict__ p_tail,
+                                                         const double *__restrict__ Ap_tail, Coarse *__restrict__ coarse,
+                                                         Scal *__restrict__ s, double tol2, int init) {
+    __shared__ double tot[kSumSlots];
+    const int tid = threadIdx.x;
+    rows_sum_16(partial, nb, (1u << (2 + ng)) - 1u, tot);
+    const int stop = s->stop;  // uniform: only thread 0 writes it, at the very end
+    if (stop) return;
+    const int nz = 2 * ng;
+    __shared__ double ztr_s[NZMAX], y_s[NZMAX], acc_s[2];
+    if (tid == 0) {
+        double rz = tot[0], rr = tot[1];
+        const double alpha = s->alpha;
+        for (int k = 0; k < ng; ++k) {
+            x_tail[k] += alpha * p_tail[k];
+            const double rt = r_tail[k] - alpha * Ap_tail[k];
+            r_tail[k] = rt;
+            const double zt = rt * coarse->tail_minv[k];
+            zb_tail[k] = zt;
+            rz += rt * zt;
+            rr += rt * rt;
+            ztr_s[k] = tot[2 + k];
+            ztr_s[ng + k] = rt;
+        }
+        acc_s[0] = rz;
+        acc_s[1] = rr;
+    }
+    __syncthreads();
+    if (tid < nz) {  // y = Einv Z^T r, one row per thread
+        double y = 0.0;
+        for (int b = 0; b < nz; ++b) y += coarse->Einv[tid * nz + b] * ztr_s[b];
+        y_s[tid] = y;
+        coarse->y[tid] = y;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    double rz = acc_s[0];
+    const double rr = acc_s[1];
+    for (int a = 0; a < nz; ++a) rz += ztr_s[a] * y_s[a];
+    s->rz_new = rz;
+    s->rr = rr;
+    if (init) {
+        s->rz = rz;
+        s->rr0 = rr;
+        s->beta = 0.0;
+    } else {
+        s->beta = rz / s->rz;
+        s->rz = rz;
+        s->iters += 1;
+        if (!(rr > tol2 * s->rr0)) s->stop = 1;
+    }
+}
+
+// z = zb + Z y; p = z + beta p
+template <int DIM>
+__global__ __launch_bounds__(NB) void cg_dir_prec_kernel(const Scal *__restrict__ s, const Coarse *__restrict__ coarse,
+                                                        const double *__restrict__ P, const double *__restrict__ v, int64_t n,
+                                                        const double *__restrict__ zb, double *__restrict__ p) {
+    constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
+    if (s->stop) return;
+    const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
+    const double beta = s->beta;
+    if (j < n) {
+        double z[NG][S];
+        zmodes<DIM>(P + j * S, v + j * DIM, z);
+        for (int e = 0; e < S; ++e) {
+            double val = zb[j * S + e];
+            for (int k = 0; k < NG; ++k) val += coarse->y[k] * z[k][e];
+            p[j * S + e] = val + beta * p[j * S + e];
+        }
+    } else if (j < n + NG) {
+        const int k = (int)(j - n);
+        p[n * S + k] = zb[n * S + k] + coarse->y[NG + k] + beta * p[n * S + k];
+    }
+}
+
 static inline int grid_for(int64_t len, int cap = 1024) {
     int64_t nb = (len + NB - 1) / NB;
     return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
@@ -697,12 +1127,16 @@ struct Work {
     double *grad, *col2, *d2, *minv;       // np
     double *delta, *rcg, *z, *pcg, *Ap;    // np
     double *x_trial;                       // np
+    double *binv;                          // n * S(S+1)/2: inverted diagonal blocks
+    Coarse *coarse;
 };
 
 static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     const Dims d = dims_of(g);
-    const size_t small = 512;  // Globals + Scal, in doubles (generous)
-    const size_t need = small + (size_t)kMaxPartials * kSumSlots + 2 * (size_t)d.n * d.dim + 3 * (size_t)d.nr + 10 * (size_t)d.np + 64;
+    const size_t small = 1024;  // Globals + Scal + Coarse, in doubles (generous)
+    const size_t tri = (size_t)d.S * (d.S + 1) / 2;
+    const size_t need = small + (size_t)kMaxPartials * kSumSlots + 2 * (size_t)d.n * d.dim + 3 * (size_t)d.nr + 10 * (size_t)d.np +
+                        (size_t)d.n * tri + 64;
     if (g->ws_doubles < need) {
         if (g->ws) {
             ICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -718,6 +1152,7 @@ static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     double *p = g->ws;
     w.glob = (Globals *)p;
     w.scal = (Scal *)(p + 256);
+    w.coarse = (Coarse *)(p + 512);
     p += small;
     w.partial = p; p += (size_t)kMaxPartials * kSumSlots;
     w.pre = p; p += (size_t)d.n * d.dim;
@@ -730,6 +1165,7 @@ static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
         *b = p;
         p += d.np;
     }
+    w.binv = p;
     return ICP_OK;
 }
 
@@ -783,7 +1219,8 @@ static int apply_J(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, const 
 
 // out = J^T u (+ lam d2 .* p_in); square: out = column sums of squares of J
 static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, const double *v, const double *c, bool compat,
-                    const double *u, const double *lam_d2, const double *p_in, double lam, double *out, bool square) {
+                    const double *u, const double *lam_d2, const double *p_in, double lam, double *out, bool square,
+                    bool finish_tail = true) {
     const Dims d = dims_of(g);
     const int nbk = grid_for(g->n, 1 << 30);
     const double *rs = compat ? w.dd : w.pre;
@@ -803,6 +1240,7 @@ static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, const
                                          c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial));
     }
     ICP_HIP_CHECK(hipGetLastError());
+    if (!finish_tail) return ICP_OK;  // the caller's fused kernel sums the partial rows
     hipLaunchKernelGGL(tail_kernel, dim3(1), dim3(NB), 0, ctx->stream, w.partial, nbk, d.NG,
                        lam_d2 ? lam_d2 + d.n * d.S : nullptr, p_in ? p_in + d.n * d.S : nullptr, lam, out + d.n * d.S);
     ICP_HIP_CHECK(hipGetLastError());
@@ -815,6 +1253,40 @@ static int dot_to(icp_ctx *ctx, Work &w, const double *a, const double *b, const
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, ctx->stream, (const double *)w.partial, nbk, out_dev);
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
+}
+
+// inverse of a small symmetric positive (semi-)definite matrix by Gauss-Jordan with partial pivoting
+static bool invert_spd(const double *E, int nz, double *out) {
+    double a[NZMAX][2 * NZMAX];
+    for (int i = 0; i < nz; ++i)
+        for (int j = 0; j < nz; ++j) {
+            const double v = 0.5 * (E[i * nz + j] + E[j * nz + i]);
+            if (!(v == v) || std::isinf(v)) return false;
+            a[i][j] = v;
+            a[i][nz + j] = i == j ? 1.0 : 0.0;
+        }
+    double scale = 0.0;
+    for (int i = 0; i < nz; ++i) scale = std::max(scale, std::fabs(a[i][i]));
+    if (!(scale > 0.0)) return false;
+    for (int c = 0; c < nz; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < nz; ++r)
+            if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (std::fabs(a[piv][c]) < 1e-14 * scale) return false;
+        if (piv != c)
+            for (int k = 0; k < 2 * nz; ++k) std::swap(a[piv][k], a[c][k]);
+        const double inv = 1.0 / a[c][c];
+        for (int k = 0; k < 2 * nz; ++k) a[c][k] *= inv;
+        for (int r = 0; r < nz; ++r) {
+            if (r == c) continue;
+            const double f = a[r][c];
+            if (f != 0.0)
+                for (int k = 0; k < 2 * nz; ++k) a[r][k] -= f * a[c][k];
+        }
+    }
+    for (int i = 0; i < nz; ++i)
+        for (int j = 0; j < nz; ++j) out[i * nz + j] = 0.5 * (a[i][nz + j] + a[j][nz + i]);
+    return true;
 }
 
 static int read_scal(icp_ctx *ctx, const Scal *dev, Scal &host) {
@@ -1014,34 +1486,59 @@ extern "C" int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const do
                 if (int rc = linearise(ctx, g, w, x, v)) return rc;
             hipLaunchKernelGGL(scaling_kernel, dim3(nbp), dim3(NB), 0, st, w.col2, w.d2, w.minv, lam, first_scaling ? 1 : 0, d.np);
             first_scaling = false;
-            // ---- CG on (J^T J + lam D^2) delta = -grad, Jacobi preconditioner
+            // ---- two-level preconditioner for (J^T J + lam D^2): inverted vertex blocks + coarse space
+            const int nbv = (int)((d.n + NB - 1) / NB), nbt = (int)((d.n + d.NG + NB - 1) / NB), nz = 2 * d.NG;
+            double *x_tail = w.delta + d.n * d.S, *r_tail = w.rcg + d.n * d.S, *zb_tail = w.z + d.n * d.S;
+            double *p_tail = w.pcg + d.n * d.S, *Ap_tail = w.Ap + d.n * d.S;
+            NICP_DISPATCH(g->dim, compat,
+                          hipLaunchKernelGGL((block_diag_kernel<D, C>), dim3((unsigned)((d.n + 63) / 64)), dim3(64), 0, st, (const double *)x,
+                                             (const double *)g->wt, g->k, v, (const int32_t *)g->edges, (const int32_t *)g->rev_ptr,
+                                             (const int32_t *)g->rev_ent, (const int32_t *)g->inc_ptr, (const int32_t *)g->inc_ent, d.n,
+                                             (const Globals *)w.glob, c[0], c[1], c[2], (const double *)w.col2, (const double *)w.d2, lam,
+                                             w.binv, w.coarse));
+            ICP_HIP_CHECK(hipGetLastError());
+            for (int a = 0; a < nz; ++a) {  // E[:, a] = Z^T (J^T J + lam D^2) z_a
+                if (g->dim == 3) hipLaunchKernelGGL(zcol_kernel<3>, dim3(nbt), dim3(NB), 0, st, (const double *)x, v, d.n, a, w.z);
+                else hipLaunchKernelGGL(zcol_kernel<2>, dim3(nbt), dim3(NB), 0, st, (const double *)x, v, d.n, a, w.z);
+                if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.z, w.y)) return rc;
+                if (int rc = apply_JT(ctx, g, w, x, v, c, compat, w.y, w.d2, w.z, lam, w.Ap, false)) return rc;
+                if (g->dim == 3) hipLaunchKernelGGL(zt_kernel<3>, dim3(nbv), dim3(NB), 0, st, (const double *)x, v, d.n, (const double *)w.Ap, w.partial);
+                else hipLaunchKernelGGL(zt_kernel<2>, dim3(nbv), dim3(NB), 0, st, (const double *)x, v, d.n, (const double *)w.Ap, w.partial);
+                hipLaunchKernelGGL(ecol_kernel, dim3(1), dim3(NB), 0, st, (const double *)w.partial, nbv, d.NG, (const double *)Ap_tail, a, w.coarse);
+            }
+            ICP_HIP_CHECK(hipGetLastError());
+            {
+                double E[NZMAX * NZMAX], Einv[NZMAX * NZMAX];
+                ICP_HIP_CHECK(hipMemcpyAsync(E, w.coarse->E, sizeof(double) * nz * nz, hipMemcpyDeviceToHost, st));
+                ICP_HIP_CHECK(hipStreamSynchronize(st));
+                if (!invert_spd(E, nz, Einv)) std::memset(Einv, 0, sizeof(Einv));  // fall back to the block level alone
+                ICP_HIP_CHECK(hipMemcpyAsync(w.coarse->Einv, Einv, sizeof(double) * nz * nz, hipMemcpyHostToDevice, st));
+            }
+            // ---- preconditioned CG on (J^T J + lam D^2) delta = -grad
             ICP_HIP_CHECK(hipMemsetAsync(w.delta, 0, d.np * sizeof(double), st));
             ICP_HIP_CHECK(hipMemsetAsync(w.pcg, 0, d.np * sizeof(double), st));
             ICP_HIP_CHECK(hipMemsetAsync(w.Ap, 0, d.np * sizeof(double), st));
             hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, -1.0, w.grad, 0.0, (const double *)nullptr, w.rcg, d.np);
             ICP_HIP_CHECK(hipMemsetAsync(w.scal, 0, sizeof(Scal), st));
-            // z = M^-1 r ; p = z ; rz = r.z ; rr0 = r.r
-            hipLaunchKernelGGL(cg_update_kernel, dim3(nbp), dim3(NB), 0, st, (const Scal *)w.scal, w.delta, w.rcg, w.z, w.pcg, w.Ap, w.minv, d.np,
-                               w.partial, w.partial + kMaxPartials);  // alpha = 0: only builds z and the dots
-            hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, st, (const double *)w.partial, nbp, &w.scal->rz);
-            hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, st, (const double *)(w.partial + kMaxPartials), nbp, &w.scal->rr0);
-            hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, 1.0, w.z, 0.0, (const double *)nullptr, w.pcg, d.np);
+            auto precondition = [&](int init) {
+                if (g->dim == 3) hipLaunchKernelGGL(cg_update_prec_kernel<3>, dim3(nbv), dim3(NB), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial);
+                else hipLaunchKernelGGL(cg_update_prec_kernel<2>, dim3(nbv), dim3(NB), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial);
+                hipLaunchKernelGGL(cg_coarse_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, d.NG, x_tail, r_tail, zb_tail,
+                                   (const double *)p_tail, (const double *)Ap_tail, w.coarse, w.scal, o.cg_tol * o.cg_tol, init);
+                if (g->dim == 3) hipLaunchKernelGGL(cg_dir_prec_kernel<3>, dim3(nbt), dim3(NB), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg);
+                else hipLaunchKernelGGL(cg_dir_prec_kernel<2>, dim3(nbt), dim3(NB), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg);
+            };
+            precondition(1);  // alpha = 0: z = M^-1 r, rz, rr0, p = z
             ICP_HIP_CHECK(hipGetLastError());
             int cg_done = 0;
             for (int ci = 0; ci < o.max_cg_iters && !cg_done;) {
                 const int chunk = std::min(50, o.max_cg_iters - ci);
                 for (int k = 0; k < chunk; ++k) {
                     if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.pcg, w.y)) return rc;
-                    if (int rc = apply_JT(ctx, g, w, x, v, c, compat, w.y, w.d2, w.pcg, lam, w.Ap, false)) return rc;
-                    hipLaunchKernelGGL(dot_kernel, dim3(nbp), dim3(NB), 0, st, w.pcg, w.Ap, (const double *)nullptr, d.np, w.partial);
-                    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, st, (const double *)w.partial, nbp, &w.scal->pAp);
-                    hipLaunchKernelGGL(cg_alpha_kernel, dim3(1), dim3(1), 0, st, w.scal);
-                    hipLaunchKernelGGL(cg_update_kernel, dim3(nbp), dim3(NB), 0, st, (const Scal *)w.scal, w.delta, w.rcg, w.z, w.pcg, w.Ap,
-                                       w.minv, d.np, w.partial, w.partial + kMaxPartials);
-                    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, st, (const double *)w.partial, nbp, &w.scal->rz_new);
-                    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, st, (const double *)(w.partial + kMaxPartials), nbp, &w.scal->rr);
-                    hipLaunchKernelGGL(cg_beta_kernel, dim3(1), dim3(1), 0, st, w.scal, o.cg_tol * o.cg_tol);
-                    hipLaunchKernelGGL(cg_dir_kernel, dim3(nbp), dim3(NB), 0, st, (const Scal *)w.scal, w.pcg, w.z, d.np);
+                    if (int rc = apply_JT(ctx, g, w, x, v, c, compat, w.y, w.d2, w.pcg, lam, w.Ap, false, false)) return rc;
+                    hipLaunchKernelGGL(cg_tail_alpha_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, d.NG,
+                                       (const double *)(w.d2 + d.n * d.S), (const double *)p_tail, lam, Ap_tail, w.scal);
+                    precondition(0);
                 }
                 ICP_HIP_CHECK(hipGetLastError());
                 ci += chunk;
