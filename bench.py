@@ -169,6 +169,13 @@ def main():
                         "the kernel is cache-latency-bound (gathers from the L2/MALL-resident sorted target), so the "
                         "HBM fraction is low by construction; equivalent brute-force rate = %.3g pair-evaluations/s"
                         % (gbytes / 1e6, pairs / t_kernel)}
+        try:   # HBM-side bytes per launch from the committed PMC passes (profiles/r1_pmc_grid.txt); valid for the default size only
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            if n == (1 << 20) and world == 1:
+                roof["traffic"] = tr["traffic_bytes"]
+                roof["traffic_source"] = tr["source"]
+        except Exception:
+            pass
         if t_brute is not None:
             ab = 8.0 * pairs / t_brute / 1e12
             roof["bruteforce_kernel"] = {"bound": "valu", "achieved": ab, "peak": FP64_VECTOR_PEAK_TFLOPS,
