@@ -59,6 +59,7 @@ _SIGNATURES = {
     "nicp_jvp": [c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_dp, c_dp],
     "nicp_jtvp": [c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_dp, c_dp],
     "nicp_solve": [c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_dp, c_dp],
+    "nicp_solve_dist": [c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_dp, c_dp, c_dp],
     "nicp_run": [c_dp, c_dp, c_dp, c_dp, c_dp, c_i64, c_dbl, c_int, c_dp, c_u32, c_dp, c_dp, c_dp, c_dp],
 }
 

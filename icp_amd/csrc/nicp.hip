@@ -409,7 +409,7 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
                                                 const Globals *__restrict__ g, double c_fit, double c_rigid,
                                                 double c_smooth, const double *__restrict__ lam_d2,
                                                 const double *__restrict__ p_in, double lam, double *__restrict__ out,
-                                                double *__restrict__ partial) {
+                                                double *__restrict__ partial, int64_t nown) {
     constexpr int S = Lay<DIM>::S, NRIG = Lay<DIM>::NRIG, NANG = Lay<DIM>::NANG, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
     const double *u_rig = u + n * DIM, *u_sm = u + n * DIM + n * NRIG;
@@ -534,7 +534,12 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
 #pragma unroll
         for (int o = 0; o < DIM; ++o) gacc[NANG + o] = SQUARE ? c_fit * c_fit : -c_fit * u[j * DIM + o];
     }
-    // block partial of the NG global entries + p.Ap (reduced by tail_kernel / cg_tail_alpha_kernel)
+    // halo copies (j >= nown) belong to another rank's sums
+    if (j >= nown) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gacc[k] = 0.0;
+    }
+    // block partial of the NG global entries + p.Ap (summed by rows_sum_kernel)
     __shared__ double red[NB / 64][9];
     const int tid = threadIdx.x;
 #pragma unroll
@@ -548,25 +553,6 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
         double s = red[0][tid];
         for (int w = 1; w < NB / 64; ++w) s += red[w][tid];
         partial[(int64_t)blockIdx.x * kSumSlots + tid] = s;
-    }
-}
-
-// tail of J^T u: sum the per-block partials of the NG global entries
-__global__ void tail_kernel(const double *__restrict__ partial, int nb, int ng, const double *__restrict__ lam_d2,
-                            const double *__restrict__ p_in, double lam, double *__restrict__ out_tail) {
-    __shared__ double red[NB];
-    const int tid = threadIdx.x;
-    for (int k = 0; k < ng; ++k) {
-        double s = 0.0;
-        for (int b = tid; b < nb; b += NB) s += partial[(int64_t)b * kSumSlots + k];
-        red[tid] = s;
-        __syncthreads();
-        for (int o = NB / 2; o > 0; o >>= 1) {
-            if (tid < o) red[tid] += red[tid + o];
-            __syncthreads();
-        }
-        if (tid == 0) out_tail[k] = red[0] + (lam_d2 ? lam * lam_d2[k] * p_in[k] : 0.0);
-        __syncthreads();
     }
 }
 
@@ -884,7 +870,7 @@ __global__ __launch_bounds__(NB) void zcol_kernel(const double *__restrict__ P, 
 // partial[b][k] = sum over the block's vertices of z_k(j) . r_j  (k < NG)
 template <int DIM>
 __global__ __launch_bounds__(NB) void zt_kernel(const double *__restrict__ P, const double *__restrict__ v, int64_t n,
-                                               const double *__restrict__ r, double *__restrict__ partial) {
+                                               const double *__restrict__ r, double *__restrict__ partial) {  // n = owned vertices
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
     double acc[NG];
@@ -908,123 +894,59 @@ __global__ __launch_bounds__(NB) void zt_kernel(const double *__restrict__ P, co
         partial[(int64_t)blockIdx.x * kSumSlots + tid] = s;
     }
 }
-// E[:, a] = [sum_b partial[b][0..NG) | w_tail[0..NG)]   (single block)
-__global__ void ecol_kernel(const double *__restrict__ partial, int nb, int ng, const double *__restrict__ w_tail, int a,
-                            Coarse *__restrict__ coarse) {
-    __shared__ double red[NB];
-    const int tid = threadIdx.x;
-    const int nz = 2 * ng;
-    for (int k = 0; k < ng; ++k) {
-        double s = 0.0;
-        for (int b = tid; b < nb; b += NB) s += partial[(int64_t)b * kSumSlots + k];
-        red[tid] = s;
-        __syncthreads();
-        for (int o = NB / 2; o > 0; o >>= 1) {
-            if (tid < o) red[tid] += red[tid + o];
-            __syncthreads();
-        }
-        if (tid == 0) {
-            coarse->E[k * nz + a] = red[0];
-            coarse->E[(ng + k) * nz + a] = w_tail[k];
-        }
-        __syncthreads();
-    }
-}
-
-// tot[k] = sum_b partial[b][k] for the slots listed in `mask`; one wave per slot (blockDim = 64 * 16)
-__device__ __forceinline__ void rows_sum_16(const double *__restrict__ partial, int nb, unsigned mask, double *tot) {
+// tot[off + k] = sum_b partial[b][k] for the slots in `mask`: one wave per slot (single block of 1024).
+// Every reduction below is "block partials -> rows_sum -> [all-reduce over ranks] -> logic kernel", so the
+// sharded solver only inserts the all-reduce; the summation tree is fixed, hence deterministic.
+__global__ __launch_bounds__(1024) void rows_sum_kernel(const double *__restrict__ partial, int nb, unsigned mask,
+                                                        double *__restrict__ tot, int off) {
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k < kSumSlots && ((mask >> k) & 1u)) {
         double a = 0.0;
         for (int b = lane; b < nb; b += 64) a += partial[(int64_t)b * kSumSlots + k];
         a = wave_sum(a);
-        if (lane == 0) tot[k] = a;
-    }
-    __syncthreads();
-}
-
-// after J^T: finish the tail of A p, p.Ap and alpha  (single block)
-__global__ __launch_bounds__(1024) void cg_tail_alpha_kernel(const double *__restrict__ partial, int nb, int ng,
-                                                             const double *__restrict__ d2_tail,
-                                                             const double *__restrict__ p_tail, double lam,
-                                                             double *__restrict__ Ap_tail, Scal *__restrict__ s) {
-    __shared__ double tot[kSumSlots];
-    const int tid = threadIdx.x;
-    rows_sum_16(partial, nb, ((1u << ng) - 1u) | (1u << 8), tot);
-    if (tid == 0 && !s->stop) {
-        double pap = tot[8];
-        for (int k = 0; k < ng; ++k) {
-            const double val = tot[k] + lam * d2_tail[k] * p_tail[k];
-            Ap_tail[k] = val;
-            pap += val * p_tail[k];
-        }
-        s->pAp = pap;
-        s->alpha = pap > 0 ? s->rz / pap : 0.0;
-        if (!(pap > 0)) s->stop = 2;  // breakdown (non-positive curvature / NaN)
+        if (lane == 0) tot[off + k] = a;
     }
 }
 
-// x += alpha p; r -= alpha Ap; zb = Binv r (per vertex); partials: r.zb, r.r, Z^T r
-template <int DIM>
-__global__ __launch_bounds__(NB) void cg_update_prec_kernel(const Scal *__restrict__ s, const double *__restrict__ P,
-                                                           const double *__restrict__ v, int64_t n,
-                                                           double *__restrict__ x, double *__restrict__ r,
-                                                           double *__restrict__ zb, const double *__restrict__ p,
-                                                           const double *__restrict__ Ap, const double *__restrict__ binv,
-                                                           double *__restrict__ partial) {
-    constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG, TRI = S * (S + 1) / 2;
-    const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
-    double acc[2 + NG];
-    for (int k = 0; k < 2 + NG; ++k) acc[k] = 0.0;
-    if (j < n && !s->stop) {
-        const double alpha = s->alpha;
-        double rj[S], zj[S];
-        for (int e = 0; e < S; ++e) {
-            x[j * S + e] += alpha * p[j * S + e];
-            rj[e] = r[j * S + e] - alpha * Ap[j * S + e];
-            r[j * S + e] = rj[e];
-            zj[e] = 0.0;
-        }
-        const double *B = binv + j * TRI;
-        int q = 0;
-        for (int a = 0; a < S; ++a)
-            for (int b = 0; b <= a; ++b) {
-                const double m = B[q++];
-                zj[a] += m * rj[b];
-                if (a != b) zj[b] += m * rj[a];
-            }
-        double z[NG][S];
-        zmodes<DIM>(P + j * S, v + j * DIM, z);
-        for (int e = 0; e < S; ++e) {
-            zb[j * S + e] = zj[e];
-            acc[0] += rj[e] * zj[e];
-            acc[1] += rj[e] * rj[e];
-            for (int k = 0; k < NG; ++k) acc[2 + k] += z[k][e] * rj[e];
-        }
-    }
-    __shared__ double red[NB / 64][2 + NG];
-    const int tid = threadIdx.x;
-    for (int k = 0; k < 2 + NG; ++k) {
-        const double t = wave_sum(acc[k]);
-        if ((tid & 63) == 0) red[tid >> 6][k] = t;
-    }
-    __syncthreads();
-    if (tid < 2 + NG) {
-        double t = red[0][tid];
-        for (int w = 1; w < NB / 64; ++w) t += red[w][tid];
-        partial[(int64_t)blockIdx.x * kSumSlots + tid] = t;
-    }
+// out_tail[k] = tot[off + k] + lam d2_tail[k] p_tail[k]: tail of J^T u (the tail entries are replicated)
+__global__ void tail_write_kernel(const double *__restrict__ tot, int off, int ng, const double *__restrict__ d2_tail,
+                                  const double *__restrict__ p_tail, double lam, double *__restrict__ out_tail) {
+    const int k = threadIdx.x;
+    if (k < ng) out_tail[k] = tot[off + k] + (d2_tail ? lam * d2_tail[k] * p_tail[k] : 0.0);
 }
 
-// single block: tail update, coarse solve y = Einv Z^T r, r.z, beta, stop test
-__global__ __launch_bounds__(1024) void cg_coarse_kernel(const double *__restrict__ partial, int nb, int ng,
-                                                         double *__restrict__ x_tail, double *__restrict__ r_tail,
-                                                         double *__restrict__ zb_tail, const double *__restrict__ p_tail,
-                                                         const double *__restrict__ Ap_tail, Coarse *__restrict__ coarse,
-                                                         Scal *__restrict__ s, double tol2, int init) {
-    __shared__ double tot[kSumSlots];
+// E[:, a]: tot[0..ng) = Z_v^T w (vertex modes), tot[8..8+ng) = tail of J^T J z_a
+__global__ void ecol_logic_kernel(const double *__restrict__ tot, int ng, const double *__restrict__ d2_tail, double lam,
+                                  int a, Coarse *__restrict__ coarse) {
+    const int k = threadIdx.x, nz = 2 * ng;
+    if (k >= ng) return;
+    coarse->E[k * nz + a] = tot[k];
+    const double ztail = (a - ng == k) ? 1.0 : 0.0;
+    coarse->E[(ng + k) * nz + a] = tot[8 + k] + lam * d2_tail[k] * ztail;
+}
+
+// after J^T: tail of A p, p.Ap and alpha.  tot[0..ng) tail sums, tot[8] vertex part of p.Ap
+__global__ void cg_alpha_logic_kernel(const double *__restrict__ tot, int ng, const double *__restrict__ d2_tail,
+                                      const double *__restrict__ p_tail, double lam, double *__restrict__ Ap_tail,
+                                      Scal *__restrict__ s) {
+    if (threadIdx.x != 0 || s->stop) return;
+    double pap = tot[8];
+    for (int k = 0; k < ng; ++k) {
+        const double val = tot[k] + lam * d2_tail[k] * p_tail[k];
+        Ap_tail[k] = val;
+        pap += val * p_tail[k];
+    }
+    s->pAp = pap;
+    s->alpha = pap > 0 ? s->rz / pap : 0.0;
+    if (!(pap > 0)) s->stop = 2;  // breakdown (non-positive curvature / NaN)
+}
+
+// tail update, coarse solve y = Einv Z^T r, r.z, beta, stop test.  tot[0] r.zb, tot[1] r.r, tot[2..2+ng) Z_v^T r
+__global__ __launch_bounds__(64) void cg_coarse_logic_kernel(const double *__restrict__ tot, int ng, double *__restrict__ x_tail,
+                                                            double *__restrict__ r_tail, double *__restrict__ zb_tail,
+                                                            const double *__restrict__ p_tail, const double *__restrict__ Ap_tail,
+                                                            Coarse *__restrict__ coarse, Scal *__restrict__ s, double tol2, int init) {
     const int tid = threadIdx.x;
-    rows_sum_16(partial, nb, (1u << (2 + ng)) - 1u, tot);
     const int stop = s->stop;  // uniform: only thread 0 writes it, at the very end
     if (stop) return;
     const int nz = 2 * ng;
@@ -1072,16 +994,86 @@ __global__ __launch_bounds__(1024) void cg_coarse_kernel(const double *__restric
     }
 }
 
+// tot[slot] += sum_k a[k] b[k] (w ? w[k] : 1) over the ng replicated tail entries (added on one rank only)
+__global__ void add_tail_dot_kernel(double *__restrict__ tot, int slot, const double *__restrict__ a,
+                                    const double *__restrict__ b, const double *__restrict__ w, int ng) {
+    if (threadIdx.x) return;
+    double s = 0.0;
+    for (int k = 0; k < ng; ++k) s += a[k] * b[k] * (w ? w[k] : 1.0);
+    tot[slot] += s;
+}
+
+// halo packing: buf[i*S + e] = vec[idx[i]*S + e]
+__global__ __launch_bounds__(NB) void pack_kernel(const double *__restrict__ vec, const int32_t *__restrict__ idx, int64_t cnt,
+                                                 int S, double *__restrict__ buf) {
+    const int64_t t = (int64_t)blockIdx.x * NB + threadIdx.x;
+    if (t < cnt * S) buf[t] = vec[(int64_t)idx[t / S] * S + t % S];
+}
+
+// x += alpha p; r -= alpha Ap; zb = Binv r (per vertex); partials: r.zb, r.r, Z^T r.
+// Only the nown owned vertices are updated (halo copies [nown, n) are refreshed by the exchange).
+template <int DIM>
+__global__ __launch_bounds__(NB) void cg_update_prec_kernel(const Scal *__restrict__ s, const double *__restrict__ P,
+                                                           const double *__restrict__ v, int64_t n,
+                                                           double *__restrict__ x, double *__restrict__ r,
+                                                           double *__restrict__ zb, const double *__restrict__ p,
+                                                           const double *__restrict__ Ap, const double *__restrict__ binv,
+                                                           double *__restrict__ partial, int64_t nown) {
+    constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG, TRI = S * (S + 1) / 2;
+    const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
+    double acc[2 + NG];
+    for (int k = 0; k < 2 + NG; ++k) acc[k] = 0.0;
+    if (j < nown && !s->stop) {
+        const double alpha = s->alpha;
+        double rj[S], zj[S];
+        for (int e = 0; e < S; ++e) {
+            x[j * S + e] += alpha * p[j * S + e];
+            rj[e] = r[j * S + e] - alpha * Ap[j * S + e];
+            r[j * S + e] = rj[e];
+            zj[e] = 0.0;
+        }
+        const double *B = binv + j * TRI;
+        int q = 0;
+        for (int a = 0; a < S; ++a)
+            for (int b = 0; b <= a; ++b) {
+                const double m = B[q++];
+                zj[a] += m * rj[b];
+                if (a != b) zj[b] += m * rj[a];
+            }
+        double z[NG][S];
+        zmodes<DIM>(P + j * S, v + j * DIM, z);
+        for (int e = 0; e < S; ++e) {
+            zb[j * S + e] = zj[e];
+            acc[0] += rj[e] * zj[e];
+            acc[1] += rj[e] * rj[e];
+            for (int k = 0; k < NG; ++k) acc[2 + k] += z[k][e] * rj[e];
+        }
+    }
+    __shared__ double red[NB / 64][2 + NG];
+    const int tid = threadIdx.x;
+    for (int k = 0; k < 2 + NG; ++k) {
+        const double t = wave_sum(acc[k]);
+        if ((tid & 63) == 0) red[tid >> 6][k] = t;
+    }
+    __syncthreads();
+    if (tid < 2 + NG) {
+        double t = red[0][tid];
+        for (int w = 1; w < NB / 64; ++w) t += red[w][tid];
+        partial[(int64_t)blockIdx.x * kSumSlots + tid] = t;
+    }
+}
+
 // z = zb + Z y; p = z + beta p
 template <int DIM>
 __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(const Scal *__restrict__ s, const Coarse *__restrict__ coarse,
                                                         const double *__restrict__ P, const double *__restrict__ v, int64_t n,
-                                                        const double *__restrict__ zb, double *__restrict__ p) {
+                                                        const double *__restrict__ zb, double *__restrict__ p, int64_t nown) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
     if (s->stop) return;
     const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
     const double beta = s->beta;
     if (j < n) {
+        if (j >= nown) return;  // halo copy
         double z[NG][S];
         zmodes<DIM>(P + j * S, v + j * DIM, z);
         for (int e = 0; e < S; ++e) {
@@ -1129,6 +1121,7 @@ struct Work {
     double *x_trial;                       // np
     double *binv;                          // n * S(S+1)/2: inverted diagonal blocks
     Coarse *coarse;
+    double *tot;                           // 64 reduced sums (the all-reduce buffer when no comm is given)
 };
 
 static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
@@ -1153,6 +1146,8 @@ static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     w.glob = (Globals *)p;
     w.scal = (Scal *)(p + 256);
     w.coarse = (Coarse *)(p + 512);
+    w.tot = p + 896;
+    static_assert(sizeof(Globals) <= 256 * 8 && sizeof(Scal) <= 256 * 8 && sizeof(Coarse) <= 384 * 8, "small area layout");
     p += small;
     w.partial = p; p += (size_t)kMaxPartials * kSumSlots;
     w.pre = p; p += (size_t)d.n * d.dim;
@@ -1217,10 +1212,60 @@ static int apply_J(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, const 
     return ICP_OK;
 }
 
-// out = J^T u (+ lam d2 .* p_in); square: out = column sums of squares of J
-static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, const double *v, const double *c, bool compat,
-                    const double *u, const double *lam_d2, const double *p_in, double lam, double *out, bool square,
-                    bool finish_tail = true) {
+// How the solver's sums and halo copies are completed: alone (comm == nullptr) or as one rank of a
+// vertex-sharded solve (nicp_solve_dist).  Local vertices are [owned | halo]; tot is the 64-double
+// buffer every reduction lands in before the (optional) all-reduce over ranks.
+struct Par {
+    const nicp_comm *comm = nullptr;
+    int64_t nown = 0;
+    double *tot = nullptr;
+    const double *row_mask = nullptr;
+    bool sharded() const { return comm && comm->world > 1; }
+    int rank() const { return comm ? comm->rank : 0; }
+};
+
+static Par par_single(const nicp_graph *g, Work &w) {
+    Par p;
+    p.nown = g->n;
+    p.tot = w.tot;
+    return p;
+}
+
+static int allreduce(const Par &par, int count) {
+    if (!par.sharded()) return ICP_OK;
+    if (int rc = par.comm->allreduce_sum(par.comm->user, count)) {
+        set_error("nicp_solve_dist: the all-reduce callback failed (%d)", rc);
+        return ICP_ERR_COMM;
+    }
+    return ICP_OK;
+}
+
+// refresh the halo copies [nown, n) of a per-vertex vector from their owners
+static int exchange(icp_ctx *ctx, const nicp_graph *g, const Par &par, double *vec) {
+    if (!par.sharded()) return ICP_OK;
+    const nicp_comm *cm = par.comm;
+    const int S = g->dim * g->dim + g->dim;
+    if (cm->n_send > 0)
+        hipLaunchKernelGGL(pack_kernel, dim3(grid_for(cm->n_send * S, 1 << 30)), dim3(NB), 0, ctx->stream, (const double *)vec,
+                           cm->send_idx_dev, cm->n_send, S, cm->send_buf_dev);
+    ICP_HIP_CHECK(hipGetLastError());
+    if (int rc = cm->exchange(cm->user)) {
+        set_error("nicp_solve_dist: the halo-exchange callback failed (%d)", rc);
+        return ICP_ERR_COMM;
+    }
+    const int64_t nh = g->n - par.nown;
+    if (nh > 0)
+        ICP_HIP_CHECK(hipMemcpyAsync(vec + par.nown * S, cm->recv_buf_dev, (size_t)nh * S * sizeof(double), hipMemcpyDeviceToDevice,
+                                     ctx->stream));
+    return ICP_OK;
+}
+
+// out = J^T u (+ lam d2 .* p_in) on the owned vertices; square: column sums of squares of J.
+// finish_tail: also complete the NG tail entries (sum over blocks, all-reduce over ranks);
+// otherwise the block partials stay in w.partial (slots 0..NG tail, slot 8 p.Ap) for the caller.
+static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const double *P, const double *v, const double *c,
+                    bool compat, const double *u, const double *lam_d2, const double *p_in, double lam, double *out,
+                    bool square, bool finish_tail = true) {
     const Dims d = dims_of(g);
     const int nbk = grid_for(g->n, 1 << 30);
     const double *rs = compat ? w.dd : w.pre;
@@ -1232,26 +1277,44 @@ static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, const
         NICP_DISPATCH(g->dim, compat,
                       hipLaunchKernelGGL((jtu_kernel<D, C, true>), dim3(nbk), dim3(NB), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,
                                          rs, g->edges, g->rev_ptr, g->rev_ent, g->inc_ptr, g->inc_ent, g->n, g->e, w.glob,
-                                         c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial));
+                                         c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial, par.nown));
     } else {
         NICP_DISPATCH(g->dim, compat,
                       hipLaunchKernelGGL((jtu_kernel<D, C, false>), dim3(nbk), dim3(NB), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,
                                          rs, g->edges, g->rev_ptr, g->rev_ent, g->inc_ptr, g->inc_ent, g->n, g->e, w.glob,
-                                         c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial));
+                                         c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial, par.nown));
     }
     ICP_HIP_CHECK(hipGetLastError());
-    if (!finish_tail) return ICP_OK;  // the caller's fused kernel sums the partial rows
-    hipLaunchKernelGGL(tail_kernel, dim3(1), dim3(NB), 0, ctx->stream, w.partial, nbk, d.NG,
+    if (!finish_tail) return ICP_OK;
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double *)w.partial, nbk, (1u << d.NG) - 1u, par.tot, 0);
+    if (int rc = allreduce(par, d.NG)) return rc;
+    hipLaunchKernelGGL(tail_write_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)par.tot, 0, d.NG,
                        lam_d2 ? lam_d2 + d.n * d.S : nullptr, p_in ? p_in + d.n * d.S : nullptr, lam, out + d.n * d.S);
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
 }
 
-static int dot_to(icp_ctx *ctx, Work &w, const double *a, const double *b, const double *wv, int64_t len, double *out_dev) {
+// tot[slot] = sum a.b.w over len entries (this rank's share; all-reduced later by the caller)
+static int dot_slot(icp_ctx *ctx, Work &w, const Par &par, const double *a, const double *b, const double *wv, int64_t len, int slot) {
     const int nbk = grid_for(len);
     hipLaunchKernelGGL(dot_kernel, dim3(nbk), dim3(NB), 0, ctx->stream, a, b, wv, len, w.partial);
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, ctx->stream, (const double *)w.partial, nbk, out_dev);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, ctx->stream, (const double *)w.partial, nbk, par.tot + slot);
     ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+// parameter-vector dot: owned vertices + (on rank 0) the replicated tail
+static int pdot_slot(icp_ctx *ctx, const nicp_graph *g, Work &w, const Par &par, const double *a, const double *b, const double *wv, int slot) {
+    const Dims d = dims_of(g);
+    if (int rc = dot_slot(ctx, w, par, a, b, wv, par.nown * d.S, slot)) return rc;
+    if (par.rank() == 0)
+        hipLaunchKernelGGL(add_tail_dot_kernel, dim3(1), dim3(64), 0, ctx->stream, par.tot, slot, a + d.n * d.S, b + d.n * d.S,
+                           wv ? wv + d.n * d.S : nullptr, d.NG);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+static int read_tot(icp_ctx *ctx, const Par &par, int count, double *host) {
+    ICP_HIP_CHECK(hipMemcpyAsync(host, par.tot, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return ICP_OK;
 }
 
@@ -1440,14 +1503,14 @@ extern "C" int nicp_jtvp(icp_ctx *ctx, nicp_graph *g, const double *P, const dou
     NICP_ARGS(ctx, g);
     ICP_REQUIRE(P && v && c3_host && u_in && g_out, "null pointer");
     if (int rc = linearise(ctx, g, w, P, v)) return rc;
-    return apply_JT(ctx, g, w, P, v, c3_host, flags & 1u, u_in, nullptr, nullptr, 0.0, g_out, false);
+    return apply_JT(ctx, g, w, par_single(g, w), P, v, c3_host, flags & 1u, u_in, nullptr, nullptr, 0.0, g_out, false);
 }
 
-extern "C" int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, const double *nn,
-                          const double *c3_host, unsigned flags, const nicp_solve_opts *opts_in,
-                          nicp_solve_stats *stats_out) {
-    NICP_ARGS(ctx, g);
-    ICP_REQUIRE(P_inout && v && nn && c3_host, "null pointer");
+// Levenberg-Marquardt with two-level preconditioned CG; par says whether this is the whole mesh
+// or one rank's shard.  Every host decision below is taken from all-reduced sums, so the ranks
+// of a sharded solve follow the same control flow without further agreement.
+static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, double *P_inout, const double *v, const double *nn,
+                      const double *c3_host, unsigned flags, const nicp_solve_opts *opts_in, nicp_solve_stats *stats_out) {
     const bool compat = flags & 1u;
     const Dims d = dims_of(g);
     nicp_solve_opts o = {1.49012e-8, 1.49012e-8, 0.0, 1e-3, 1e-10, 100, 0};
@@ -1456,14 +1519,17 @@ extern "C" int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const do
     hipStream_t st = ctx->stream;
     const double *c = c3_host;
     Scal hs;
+    double ht[8];
     nicp_solve_stats stt = {0, 0, 0, 0, 0, 0};
     const int nbp = grid_for(d.np);
+    const int64_t nown = par.nown;
 
     double *x = P_inout;
     if (int rc = residual_at(ctx, g, w, x, v, nn, c, compat, w.r)) return rc;
-    if (int rc = dot_to(ctx, w, w.r, w.r, nullptr, d.nr, &w.scal->tmp[0])) return rc;
-    if (int rc = read_scal(ctx, w.scal, hs)) return rc;
-    double f2 = hs.tmp[0];
+    if (int rc = dot_slot(ctx, w, par, w.r, w.r, par.row_mask, d.nr, 0)) return rc;
+    if (int rc = allreduce(par, 1)) return rc;
+    if (int rc = read_tot(ctx, par, 1, ht)) return rc;
+    double f2 = ht[0];
     stt.err0 = f2;
     stt.nfev = 1;
     double lam = o.lambda0, nu = 2.0;
@@ -1477,8 +1543,8 @@ extern "C" int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const do
         }
         // linearise at x (w.r holds r(x) and w.pre/dd/glob are those of x after residual_at)
         if (int rc = linearise(ctx, g, w, x, v)) return rc;
-        if (int rc = apply_JT(ctx, g, w, x, v, c, compat, w.r, nullptr, nullptr, 0.0, w.grad, false)) return rc;
-        if (int rc = apply_JT(ctx, g, w, x, v, c, compat, w.r, nullptr, nullptr, 0.0, w.col2, true)) return rc;
+        if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.r, nullptr, nullptr, 0.0, w.grad, false)) return rc;
+        if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.r, nullptr, nullptr, 0.0, w.col2, true)) return rc;
         bool accepted = false;
         bool relinearise = false;
         while (!accepted && !info) {
@@ -1487,9 +1553,12 @@ extern "C" int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const do
             hipLaunchKernelGGL(scaling_kernel, dim3(nbp), dim3(NB), 0, st, w.col2, w.d2, w.minv, lam, first_scaling ? 1 : 0, d.np);
             first_scaling = false;
             // ---- two-level preconditioner for (J^T J + lam D^2): inverted vertex blocks + coarse space
-            const int nbv = (int)((d.n + NB - 1) / NB), nbt = (int)((d.n + d.NG + NB - 1) / NB), nz = 2 * d.NG;
+            const int nbv = (int)((nown + NB - 1) / NB), nbt = (int)((d.n + d.NG + NB - 1) / NB), nz = 2 * d.NG;
+            const int nbj = grid_for(d.n, 1 << 30);  // blocks of the J^T kernel (all local vertices)
+            const unsigned ng_mask = (1u << d.NG) - 1u;
             double *x_tail = w.delta + d.n * d.S, *r_tail = w.rcg + d.n * d.S, *zb_tail = w.z + d.n * d.S;
             double *p_tail = w.pcg + d.n * d.S, *Ap_tail = w.Ap + d.n * d.S;
+            const double *d2_tail = w.d2 + d.n * d.S;
             NICP_DISPATCH(g->dim, compat,
                           hipLaunchKernelGGL((block_diag_kernel<D, C>), dim3((unsigned)((d.n + 63) / 64)), dim3(64), 0, st, (const double *)x,
                                              (const double *)g->wt, g->k, v, (const int32_t *)g->edges, (const int32_t *)g->rev_ptr,
@@ -1501,10 +1570,13 @@ extern "C" int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const do
                 if (g->dim == 3) hipLaunchKernelGGL(zcol_kernel<3>, dim3(nbt), dim3(NB), 0, st, (const double *)x, v, d.n, a, w.z);
                 else hipLaunchKernelGGL(zcol_kernel<2>, dim3(nbt), dim3(NB), 0, st, (const double *)x, v, d.n, a, w.z);
                 if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.z, w.y)) return rc;
-                if (int rc = apply_JT(ctx, g, w, x, v, c, compat, w.y, w.d2, w.z, lam, w.Ap, false)) return rc;
-                if (g->dim == 3) hipLaunchKernelGGL(zt_kernel<3>, dim3(nbv), dim3(NB), 0, st, (const double *)x, v, d.n, (const double *)w.Ap, w.partial);
-                else hipLaunchKernelGGL(zt_kernel<2>, dim3(nbv), dim3(NB), 0, st, (const double *)x, v, d.n, (const double *)w.Ap, w.partial);
-                hipLaunchKernelGGL(ecol_kernel, dim3(1), dim3(NB), 0, st, (const double *)w.partial, nbv, d.NG, (const double *)Ap_tail, a, w.coarse);
+                if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.y, w.d2, w.z, lam, w.Ap, false, false)) return rc;
+                hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask, par.tot, 8);
+                if (g->dim == 3) hipLaunchKernelGGL(zt_kernel<3>, dim3(nbv), dim3(NB), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial);
+                else hipLaunchKernelGGL(zt_kernel<2>, dim3(nbv), dim3(NB), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial);
+                hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, ng_mask, par.tot, 0);
+                if (int rc = allreduce(par, 16)) return rc;
+                hipLaunchKernelGGL(ecol_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, d2_tail, lam, a, w.coarse);
             }
             ICP_HIP_CHECK(hipGetLastError());
             {
@@ -1520,25 +1592,30 @@ extern "C" int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const do
             ICP_HIP_CHECK(hipMemsetAsync(w.Ap, 0, d.np * sizeof(double), st));
             hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, -1.0, w.grad, 0.0, (const double *)nullptr, w.rcg, d.np);
             ICP_HIP_CHECK(hipMemsetAsync(w.scal, 0, sizeof(Scal), st));
-            auto precondition = [&](int init) {
-                if (g->dim == 3) hipLaunchKernelGGL(cg_update_prec_kernel<3>, dim3(nbv), dim3(NB), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial);
-                else hipLaunchKernelGGL(cg_update_prec_kernel<2>, dim3(nbv), dim3(NB), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial);
-                hipLaunchKernelGGL(cg_coarse_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, d.NG, x_tail, r_tail, zb_tail,
+            auto precondition = [&](int init) -> int {
+                if (g->dim == 3) hipLaunchKernelGGL(cg_update_prec_kernel<3>, dim3(nbv), dim3(NB), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial, nown);
+                else hipLaunchKernelGGL(cg_update_prec_kernel<2>, dim3(nbv), dim3(NB), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial, nown);
+                hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, (1u << (2 + d.NG)) - 1u, par.tot, 0);
+                if (int rc = allreduce(par, 2 + d.NG)) return rc;
+                hipLaunchKernelGGL(cg_coarse_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, x_tail, r_tail, zb_tail,
                                    (const double *)p_tail, (const double *)Ap_tail, w.coarse, w.scal, o.cg_tol * o.cg_tol, init);
-                if (g->dim == 3) hipLaunchKernelGGL(cg_dir_prec_kernel<3>, dim3(nbt), dim3(NB), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg);
-                else hipLaunchKernelGGL(cg_dir_prec_kernel<2>, dim3(nbt), dim3(NB), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg);
+                if (g->dim == 3) hipLaunchKernelGGL(cg_dir_prec_kernel<3>, dim3(nbt), dim3(NB), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown);
+                else hipLaunchKernelGGL(cg_dir_prec_kernel<2>, dim3(nbt), dim3(NB), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown);
+                return exchange(ctx, g, par, w.pcg);
             };
-            precondition(1);  // alpha = 0: z = M^-1 r, rz, rr0, p = z
+            if (int rc = precondition(1)) return rc;  // alpha = 0: z = M^-1 r, rz, rr0, p = z
             ICP_HIP_CHECK(hipGetLastError());
             int cg_done = 0;
             for (int ci = 0; ci < o.max_cg_iters && !cg_done;) {
                 const int chunk = std::min(50, o.max_cg_iters - ci);
                 for (int k = 0; k < chunk; ++k) {
                     if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.pcg, w.y)) return rc;
-                    if (int rc = apply_JT(ctx, g, w, x, v, c, compat, w.y, w.d2, w.pcg, lam, w.Ap, false, false)) return rc;
-                    hipLaunchKernelGGL(cg_tail_alpha_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, d.NG,
-                                       (const double *)(w.d2 + d.n * d.S), (const double *)p_tail, lam, Ap_tail, w.scal);
-                    precondition(0);
+                    if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.y, w.d2, w.pcg, lam, w.Ap, false, false)) return rc;
+                    hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask | (1u << 8), par.tot, 0);
+                    if (int rc = allreduce(par, 9)) return rc;
+                    hipLaunchKernelGGL(cg_alpha_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, d2_tail,
+                                       (const double *)p_tail, lam, Ap_tail, w.scal);
+                    if (int rc = precondition(0)) return rc;
                 }
                 ICP_HIP_CHECK(hipGetLastError());
                 ci += chunk;
@@ -1546,18 +1623,20 @@ extern "C" int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const do
                 cg_done = hs.stop;
             }
             stt.cg_iters += hs.iters;
+            if (int rc = exchange(ctx, g, par, w.delta)) return rc;
             // ---- trial point and gain ratio
             hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, 1.0, (const double *)x, 1.0, (const double *)w.delta, w.x_trial, d.np);
             // predicted reduction of |r|^2 : delta^T (lam D^2 delta - grad)
-            if (int rc = dot_to(ctx, w, w.delta, w.delta, w.d2, d.np, &w.scal->tmp[1])) return rc;   // |D delta|^2
-            if (int rc = dot_to(ctx, w, w.delta, w.grad, nullptr, d.np, &w.scal->tmp[2])) return rc;
-            if (int rc = dot_to(ctx, w, x, x, w.d2, d.np, &w.scal->tmp[3])) return rc;               // |D x|^2
-            if (int rc = dot_to(ctx, w, w.grad, w.grad, nullptr, d.np, &w.scal->tmp[4])) return rc;
+            if (int rc = pdot_slot(ctx, g, w, par, w.delta, w.delta, w.d2, 1)) return rc;   // |D delta|^2
+            if (int rc = pdot_slot(ctx, g, w, par, w.delta, w.grad, nullptr, 2)) return rc;
+            if (int rc = pdot_slot(ctx, g, w, par, x, x, w.d2, 3)) return rc;               // |D x|^2
+            if (int rc = pdot_slot(ctx, g, w, par, w.grad, w.grad, nullptr, 4)) return rc;
             if (int rc = residual_at(ctx, g, w, w.x_trial, v, nn, c, compat, w.r_trial)) return rc;
-            if (int rc = dot_to(ctx, w, w.r_trial, w.r_trial, nullptr, d.nr, &w.scal->tmp[0])) return rc;
-            if (int rc = read_scal(ctx, w.scal, hs)) return rc;
+            if (int rc = dot_slot(ctx, w, par, w.r_trial, w.r_trial, par.row_mask, d.nr, 0)) return rc;
+            if (int rc = allreduce(par, 5)) return rc;
+            if (int rc = read_tot(ctx, par, 5, ht)) return rc;
             stt.nfev++;
-            const double f2t = hs.tmp[0], dn2 = hs.tmp[1], dg = hs.tmp[2], xn2 = hs.tmp[3], gg = hs.tmp[4];
+            const double f2t = ht[0], dn2 = ht[1], dg = ht[2], xn2 = ht[3], gg = ht[4];
             const double pred = lam * dn2 - dg;  // = |r|^2 - |r + J delta|^2 - lam|D delta|^2 ... >= 0 for an exact solve
             const double actred = f2 - f2t;
             const double ratio = pred > 0 ? actred / pred : (actred > 0 ? 1.0 : -1.0);
@@ -1590,6 +1669,41 @@ extern "C" int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const do
     if (stats_out) *stats_out = stt;
     ICP_HIP_CHECK(hipStreamSynchronize(st));
     return ICP_OK;
+}
+
+extern "C" int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, const double *nn,
+                          const double *c3_host, unsigned flags, const nicp_solve_opts *opts_in,
+                          nicp_solve_stats *stats_out) {
+    NICP_ARGS(ctx, g);
+    ICP_REQUIRE(P_inout && v && nn && c3_host, "null pointer");
+    return solve_impl(ctx, g, w, par_single(g, w), P_inout, v, nn, c3_host, flags, opts_in, stats_out);
+}
+
+extern "C" int nicp_solve_dist(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, const double *nn,
+                               const double *c3_host, unsigned flags, const nicp_solve_opts *opts_in,
+                               nicp_solve_stats *stats_out, const nicp_comm *comm) {
+    NICP_ARGS(ctx, g);
+    ICP_REQUIRE(P_inout && v && nn && c3_host && comm, "null pointer");
+    ICP_REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, "bad rank / world");
+    ICP_REQUIRE(comm->n_owned >= 0 && comm->n_owned <= g->n, "n_owned exceeds the local mesh");
+    ICP_REQUIRE(comm->n_send >= 0 && (comm->n_send == 0 || (comm->send_idx_dev && comm->send_buf_dev)), "send lists missing");
+    ICP_REQUIRE(comm->n_owned == g->n || comm->recv_buf_dev, "recv_buf_dev missing");
+    if (flags & 1u) {
+        set_error("nicp_solve_dist: NICP_REFERENCE_COMPAT does not shard (quirk Q5 couples rigid-residual slots of unrelated vertices)");
+        return ICP_ERR_UNSUPPORTED;
+    }
+    Par par;
+    par.comm = comm;
+    par.nown = comm->n_owned;
+    par.tot = w.tot;
+    if (comm->world > 1) {
+        ICP_REQUIRE(comm->reduce_buf_dev && comm->row_mask_dev && comm->allreduce_sum && comm->exchange, "comm buffers / callbacks missing");
+        par.tot = comm->reduce_buf_dev;
+        par.row_mask = comm->row_mask_dev;
+    } else {
+        ICP_REQUIRE(comm->n_owned == g->n, "a single rank owns every local vertex");
+    }
+    return solve_impl(ctx, g, w, par, P_inout, v, nn, c3_host, flags, opts_in, stats_out);
 }
 
 // NICP outer loop: nicp_3d.py:344-363 (Deform -> Match -> leastsq -> stiffness schedule).

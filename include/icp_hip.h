@@ -37,7 +37,8 @@ enum {
     ICP_ERR_HIP = -2,         /* a HIP runtime call failed */
     ICP_ERR_NOMEM = -3,       /* scratch allocation failed */
     ICP_ERR_UNSUPPORTED = -4, /* valid request this build cannot serve */
-    ICP_ERR_NUMERIC = -5      /* solver broke down (non-finite values) */
+    ICP_ERR_NUMERIC = -5,     /* solver broke down (non-finite values) */
+    ICP_ERR_COMM = -6         /* a communication callback of nicp_solve_dist reported failure */
 };
 
 /* flags for icp_closest / icp_rigid_run */
@@ -210,11 +211,44 @@ typedef struct nicp_solve_stats {
 
 /* The optimize.leastsq call of nicp_3d.py:351 / nicp_row.py:246: minimise |MinFunc(P)|^2 from
  * P_inout with correspondences nn fixed.  Levenberg-Marquardt; each step solves
- * (J^T J + lambda D^2) delta = -J^T r by Jacobi-preconditioned conjugate gradients on the
- * matrix-free operators above.  opts_host may be NULL; stats_host may be NULL.  Synchronises. */
+ * (J^T J + lambda D^2) delta = -J^T r by conjugate gradients on the matrix-free operators above,
+ * preconditioned by the inverted per-vertex blocks plus a 12-dimensional (6 in 2-D) coarse space
+ * of the modes the stiffness terms cannot see.  opts_host may be NULL; stats_host may be NULL.  Synchronises. */
 int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, const double *nn,
                const double *c3_host, unsigned flags, const nicp_solve_opts *opts_host,
                nicp_solve_stats *stats_host);
+
+/* One rank's view of a vertex-sharded solve.  The mesh is cut
+ * into vertex ranges; a rank's local mesh is [owned vertices | halo copies] with the fit rows of
+ * every vertex whose influence set touches an owned vertex and the edges with an owned endpoint
+ * (icp_amd/nicp_dist.py builds it).  The library never talks to the network itself: it calls the
+ * two callbacks below, which the host implements over RCCL / MPI / torch.distributed.  Both must be
+ * ordered after the work already queued on the context's stream and must have completed, or be
+ * ordered on that stream, when they return; they return 0 on success.  All pointers except `user`
+ * are DEVICE pointers. */
+typedef struct nicp_comm {
+    int rank, world;
+    int64_t n_owned;             /* the first n_owned local vertices are owned, the rest are halo copies */
+    double *reduce_buf_dev;      /* >= 64 doubles; allreduce_sum sums its first `count` entries over ranks in place */
+    const int32_t *send_idx_dev; /* [n_send] local ids of owned vertices that peers hold as halo, grouped by destination rank */
+    int64_t n_send;
+    double *send_buf_dev;        /* [n_send, S] packed by the library before every exchange, S = dim*dim+dim */
+    double *recv_buf_dev;        /* [n_halo, S] filled by exchange() in local halo order */
+    const double *row_mask_dev;  /* [rows] 1.0 for the residual rows this rank owns, else 0.0 (rows as in nicp_residual) */
+    void *user;
+    int (*allreduce_sum)(void *user, int count);
+    int (*exchange)(void *user);
+} nicp_comm;
+
+/* nicp_solve on one rank of a sharded mesh: same algorithm, every sum completed by allreduce_sum
+ * (<= 16 doubles each) and the search direction's halo refreshed once per CG iteration.  g is the
+ * LOCAL graph, P_inout the local parameter vector [owned | halo | tail] (tail replicated), nn the
+ * matched points of the local vertices.  stats are global.  flags must be 0: quirk Q5 of the
+ * compat mode couples rigid-residual slots of unrelated vertices and does not shard.  Every rank
+ * must call it collectively.  No counterpart in the reference (single process, dense Jacobian). */
+int nicp_solve_dist(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, const double *nn,
+                    const double *c3_host, unsigned flags, const nicp_solve_opts *opts_host,
+                    nicp_solve_stats *stats_host, const nicp_comm *comm);
 
 /* NICP: nicp_3d.py:344-363 (interactive twin nicp_row.py:243-264).  Outer loop
  * Deform -> Match -> nicp_solve; when the energy improves by less than tol, c_rigid and
