@@ -13,8 +13,8 @@ reports strong scaling (total work fixed).
 
 Prints ONE JSON line (rank 0).  `value` = closest-point queries/s over whole ICP
 iterations (= N_src * K / time); `icp_iters_per_s` is the same run in iterations.
-`roofline` is for the dominant kernel (closest point): bound by fp64 VALU, not HBM or
-MFMA -- see DESIGN.md.  `cpu_baseline` times the C oracle (test infrastructure, used
+`roofline` is for the dominant kernel (the exact grid closest-point search; --brute: the
+full-scan kernel, bound by fp64 VALU) -- see DESIGN.md section 3.  `cpu_baseline` times the C oracle (test infrastructure, used
 here only as the thing compared against) on the host cores.
 """
 import argparse
@@ -60,7 +60,7 @@ def cpu_baseline(src, tgt, sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)   # C2: 30 iterations
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=1 << 20, help="source AND target points (default 2^20)")
     ap.add_argument("--cpu-sample", type=int, default=32768)
@@ -149,7 +149,7 @@ def main():
     if args.brute:
         t_kernel = t_brute
     else:
-        t_kernel = rigid.time_grid_query(src_d, tgt_d, reps=max(3, min(K, 10)), ctx=ctx)
+        t_kernel, t_lane, t_defer = rigid.time_grid_query(src_d, tgt_d, reps=max(3, min(K, 10)), ctx=ctx, parts=True)
     if args.brute:
         achieved = 8.0 * pairs / t_kernel / 1e12
         roof = {"bound": "valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -163,12 +163,14 @@ def main():
         achieved = gbytes / t_kernel / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "grid_query_kernel<3,false>", "kernel_ms": t_kernel * 1e3,
-                "note": "exact grid search: algorithmic bytes per launch = 24 B/query + 4 B/index out + 32 B/target record "
-                        "(Morton-sorted, read at least once) + the 2^21-entry cell-start array = %.1f MB; "
-                        "the kernel is cache-latency-bound (gathers from the L2/MALL-resident sorted target), so the "
-                        "HBM fraction is low by construction; equivalent brute-force rate = %.3g pair-evaluations/s"
-                        % (gbytes / 1e6, pairs / t_kernel)}
+                "kernel": "grid search = grid_query_kernel<3,false,256,4> + grid_defer_kernel<3,false>", "kernel_ms": t_kernel * 1e3,
+                "kernel_ms_parts": {"grid_query_kernel": t_lane * 1e3, "grid_defer_kernel": t_defer * 1e3},
+                "note": "exact grid search (two launches: per-lane pass, then one wave per deferred query): algorithmic "
+                        "bytes per search = 24 B/query + 4 B/index out + 32 B/target record (Morton-sorted, read at least "
+                        "once) + the 2^21-entry cell-start array = %.1f MB; the search is bound by the L1 address/data "
+                        "path (TA busy 66-82%%) and fp64 VALU (~50%%) on gathers from the L2/MALL-resident sorted target, "
+                        "not by HBM, so the HBM fraction is low by construction; equivalent brute-force rate = %.3g "
+                        "pair-evaluations/s" % (gbytes / 1e6, pairs / t_kernel)}
         try:   # HBM-side bytes per launch from the committed PMC passes (profiles/r1_pmc_grid.txt); valid for the default size only
             tr = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
             if n == (1 << 20) and world == 1:

@@ -52,6 +52,7 @@ struct icp_ctx {
     icp::Scratch work_a, work_b, work_c, work_d;  // general work arrays
     icp::Scratch grid_a, grid_b, grid_c, grid_d, grid_e;  // spatial grid over the target
     icp::Scratch sort_a, sort_b, sort_c, sort_d;          // Morton order of the queries
+    icp::Scratch defer;                                   // grid search: queries handed to the wave-per-query pass
 };
 
 namespace icp {

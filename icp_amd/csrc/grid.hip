@@ -238,16 +238,23 @@ __device__ __forceinline__ bool better2(double da, int32_t ia, double db, int32_
 }
 
 // LE = false: argmin (d2, index).  LE = true: lowest index with d2 <= thr[q].
-template <int DIM, bool LE>
-__global__ __launch_bounds__(GB) void grid_query_kernel(const double *__restrict__ src, int64_t n,
+// A query the per-lane pass gave up on after `cap` levels: state to resume from
+struct Deferred {
+    int32_t q, level, bi, pad;
+    double best;
+};
+
+template <int DIM, bool LE, int QB, int WPE>
+__global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void grid_query_kernel(const double *__restrict__ src, int64_t n,
                                                        const int32_t *__restrict__ qorder,
                                                        const double4 *__restrict__ recs,
                                                        const uint32_t *__restrict__ start, GridParams gp,
                                                        const double *__restrict__ thr_in, int32_t *__restrict__ idx_out,
                                                        double *__restrict__ d2_out, const int32_t *__restrict__ done,
-                                                       long long *__restrict__ dbg) {
+                                                       long long *__restrict__ dbg, int cap,
+                                                       Deferred *__restrict__ deferred, uint32_t *__restrict__ n_deferred) {
     if (done && *done) return;
-    const int64_t t = (int64_t)blockIdx.x * GB + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * QB + threadIdx.x;
     if (t >= n) return;
     const long long t_begin = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
     int dbg_levels = 0, dbg_cand = 0;
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(GB) void grid_query_kernel(const double *__restrict
     // the ranges that survive its bound test, then all lanes walk their OWN concatenated list, so
     // a wave's trip count is the longest TOTAL, not the sum of per-cell maxima.
     constexpr int LIST = 8;
-    __shared__ uint2 wl[LIST][GB];
+    __shared__ uint2 wl[LIST][QB];
     const int lane_slot = threadIdx.x;
 
     auto eval = [&](const double4 &rc) {
@@ -320,6 +327,20 @@ __global__ __launch_bounds__(GB) void grid_query_kernel(const double *__restrict
     };
 
     for (int l = 0; l <= gp.bits; ++l) {
+        if (l >= cap) {
+            // A few queries (sparse regions, far outliers) need many levels and would hold their whole
+            // wave -- and, at the end of the launch, the whole GPU -- for hundreds of microseconds.
+            // They are handed to grid_defer_kernel, which gives each of them a wave of its own.
+            const uint32_t slot = atomicAdd(n_deferred, 1u);
+            Deferred dq;
+            dq.q = (int32_t)q;
+            dq.level = l;
+            dq.bi = bi;
+            dq.pad = 0;
+            dq.best = best;
+            deferred[slot] = dq;
+            return;
+        }
         ++dbg_levels;
         const double hl = gp.h * (double)(1 << l);
         const int ncl = 1 << (gp.bits - l);
@@ -442,6 +463,146 @@ __global__ __launch_bounds__(GB) void grid_query_kernel(const double *__restrict
     if (d2_out) d2_out[q] = best;
 }
 
+// Second pass: one wave per deferred query.  Same search (3^DIM neighbourhood per level, bound test,
+// gap test), but the 27 range lookups are done by 27 lanes at once and the surviving ranges are
+// scanned 64 records per step, so a query that needs many levels costs a few microseconds.
+template <int DIM, bool LE>
+__global__ __launch_bounds__(64) void grid_defer_kernel(const double *__restrict__ src, const double4 *__restrict__ recs,
+                                                        const uint32_t *__restrict__ start, GridParams gp,
+                                                        const double *__restrict__ thr_in, int32_t *__restrict__ idx_out,
+                                                        double *__restrict__ d2_out, const int32_t *__restrict__ done,
+                                                        const Deferred *__restrict__ deferred,
+                                                        const uint32_t *__restrict__ n_deferred) {
+    if (done && *done) return;
+    constexpr int NBR = DIM == 3 ? 27 : 9;
+    // one wave per block: __syncthreads() below is a wave-level fence, and the trip count is block-uniform
+    __shared__ uint32_t pre_s[1][NBR + 1], r0_s[1][NBR];
+    const int lane = threadIdx.x, wv = 0;
+    const uint32_t nd = *n_deferred;
+    const uint32_t nwaves = gridDim.x;
+    for (uint32_t it = blockIdx.x; it < nd; it += nwaves) {
+        const Deferred dq = deferred[it];
+        const int64_t q = dq.q;
+        double s[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) s[a] = src[q * DIM + a];
+        int c0[DIM];
+        cell_of<DIM>(s, gp, c0);
+        double best = dq.best;     // wave-uniform between levels
+        int32_t bi = dq.bi;
+        const double thr = LE ? thr_in[q] : 0.0;
+        for (int l = dq.level; l <= gp.bits; ++l) {
+            const double hl = gp.h * (double)(1 << l);
+            const int ncl = 1 << (gp.bits - l);
+            const double slack_h = hl * 0x1p-20;
+            // lane nb < NBR: neighbour cell nb of the query's level-l cell
+            uint32_t r0 = 0, r1 = 0;
+            int cl[DIM];
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) cl[a] = c0[a] >> l;
+            if (lane < NBR) {
+                const int off[3] = {lane % 3 - 1, (lane / 3) % 3 - 1, lane / 9 - 1};
+                bool inside = true;
+                double bound = 0.0;
+                int x[DIM];
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) {
+                    x[a] = cl[a] + off[a];
+                    inside = inside && x[a] >= 0 && x[a] < ncl;
+                    const double sl = slack_h + (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
+                    const double lo = gp.mn[a] + (double)x[a] * hl, hi = gp.mn[a] + (double)(x[a] + 1) * hl;
+                    double g = lo - s[a] - sl;
+                    const double gh = s[a] - hi - sl;
+                    g = gh > g ? gh : g;
+                    g = g > 0.0 ? g : 0.0;
+                    bound = bound + g * g;   // same association as the per-lane pass: ((gx + gy) + gz)
+                }
+                if (inside && !(LE ? (bound > thr) : (bound > best))) {
+                    const uint32_t code = morton<DIM>(x);
+                    r0 = start[(uint64_t)code << (DIM * l)];
+                    r1 = start[((uint64_t)code + 1) << (DIM * l)];
+                }
+            }
+            // exclusive prefix of the range lengths over lanes 0..NBR-1
+            uint32_t len = r1 - r0, incl = len;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const uint32_t v = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += v;
+            }
+            if (lane < NBR) {
+                pre_s[wv][lane + 1] = incl;
+                r0_s[wv][lane] = r0;
+            }
+            if (lane == 0) pre_s[wv][0] = 0;
+            __syncthreads();
+            const uint32_t total = pre_s[wv][NBR];
+            double lb = best;
+            int32_t li = bi;
+            for (uint32_t tpos = lane; tpos < total; tpos += 64) {
+                int c = 0;  // last cell with pre[c] <= tpos
+#pragma unroll
+                for (int stp = 16; stp > 0; stp >>= 1)
+                    if (c + stp < NBR && pre_s[wv][c + stp] <= tpos) c += stp;
+                const double4 rc = recs[r0_s[wv][c] + (tpos - pre_s[wv][c])];
+                const double dx = rc.x - s[0], dy = rc.y - s[1];
+                double d = dx * dx + dy * dy;
+                if (DIM == 3) {
+                    const double dz = rc.z - s[2];
+                    d = d + dz * dz;
+                }
+                const int32_t id = (int32_t)__double_as_longlong(rc.w);
+                if (LE) {
+                    if (d <= thr && id < li) {
+                        li = id;
+                        lb = 0.0;
+                    }
+                } else if (d < lb || (d == lb && id < li)) {
+                    lb = d;
+                    li = id;
+                }
+            }
+            // wave argmin of (d2, index)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = shfl_xor_f64(lb, o);
+                const int32_t oi = __shfl_xor(li, o, 64);
+                if (ob < lb || (ob == lb && oi < li)) {
+                    lb = ob;
+                    li = oi;
+                }
+            }
+            best = lb;
+            bi = li;
+            __syncthreads();  // the next level rewrites pre_s / r0_s
+            if (ncl == 1) break;
+            double mgap = __builtin_inf();
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) {
+                const double sl = slack_h + (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
+                if (cl[a] - 1 > 0) {
+                    const double g = s[a] - (gp.mn[a] + (double)(cl[a] - 1) * hl) - sl;
+                    mgap = g < mgap ? g : mgap;
+                }
+                if (cl[a] + 2 < ncl) {
+                    const double g = (gp.mn[a] + (double)(cl[a] + 2) * hl) - s[a] - sl;
+                    mgap = g < mgap ? g : mgap;
+                }
+            }
+            if (mgap == __builtin_inf()) break;
+            if (mgap > 0.0) {
+                const double m2 = mgap * mgap;
+                if (LE ? (thr < m2) : (best < m2)) break;
+            }
+        }
+        if (lane == 0) {
+            if (bi == 0x7fffffff) bi = 0;
+            idx_out[q] = bi;
+            if (d2_out) d2_out[q] = best;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host side
 static int env_bits() {
     const char *e = getenv("ICP_GRID_BITS");
@@ -526,15 +687,33 @@ int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBui
     return ICP_OK;
 }
 
-long long *g_grid_dbg = nullptr;  // temporary instrumentation hook
+long long *g_grid_dbg = nullptr;    // per-lane instrumentation (ICP_GRID_DEBUG in icp_bench_grid_query)
+hipEvent_t *g_grid_events = nullptr;  // [3]: before the per-lane pass, between the passes, after the deferred pass
 
 int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
                const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done) {
-    const unsigned nb = (unsigned)((n + GB - 1) / GB);
     hipStream_t st = ctx->stream;
+    // levels the per-lane pass handles itself (ICP_GRID_CAP=0: all of them, single pass)
+    static const int cap_env = getenv("ICP_GRID_CAP") ? atoi(getenv("ICP_GRID_CAP")) : 1;
+    const int cap = g_grid_dbg ? 1000 : (cap_env > 0 ? cap_env : 1000);
+    if (int rc = ensure(ctx, ctx->defer, (size_t)n * sizeof(Deferred) + 256)) return rc;
+    uint32_t *ndef = (uint32_t *)ctx->defer.ptr;
+    Deferred *dlist = (Deferred *)((char *)ctx->defer.ptr + 256);
+    ICP_HIP_CHECK(hipMemsetAsync(ndef, 0, sizeof(uint32_t), st));
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    unsigned nb2 = n < 8192 ? (unsigned)n : 8192u;   // one wave per deferred query, at most
 #define ICP_GQ(D, L) \
-    hipLaunchKernelGGL((grid_query_kernel<D, L>), dim3(nb), dim3(GB), 0, st, src, n, qorder, (const double4 *)gb.recs, \
-                       (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, g_grid_dbg)
+    do { \
+        if (g_grid_events) (void)hipEventRecord(g_grid_events[0], st); \
+        hipLaunchKernelGGL((grid_query_kernel<D, L, 256, 4>), dim3(nb), dim3(256), 0, st, src, n, qorder, (const double4 *)gb.recs, \
+                           (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, g_grid_dbg, cap, dlist, ndef); \
+        if (g_grid_events) (void)hipEventRecord(g_grid_events[1], st); \
+        if (cap < 1000) \
+            hipLaunchKernelGGL((grid_defer_kernel<D, L>), dim3(nb2), dim3(64), 0, st, src, (const double4 *)gb.recs, \
+                               (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (const Deferred *)dlist, \
+                               (const uint32_t *)ndef); \
+        if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
+    } while (0)
     if (gb.gp.dim == 3) {
         if (le) ICP_GQ(3, true);
         else ICP_GQ(3, false);

@@ -16,6 +16,7 @@
 
 namespace icp {
 extern long long *g_grid_dbg;
+extern hipEvent_t *g_grid_events;
 
 constexpr int RB = 256;  // threads per reduction block
 
@@ -641,7 +642,8 @@ extern "C" int icp_bench_grid_query(icp_ctx *ctx, const double *src, int64_t n, 
     int32_t *idx = (int32_t *)ctx->work_d.ptr;
     hipStream_t s = ctx->stream;
     if (int rc = grid_query(ctx, grid, q, n, nullptr, false, nullptr, idx, nullptr, nullptr)) return rc;  // warm
-    hipEvent_t e0, e1;
+    // whole search (both launches) back to back
+    hipEvent_t e0, e1, ev[3];
     ICP_HIP_CHECK(hipEventCreate(&e0));
     ICP_HIP_CHECK(hipEventCreate(&e1));
     ICP_HIP_CHECK(hipEventRecord(e0, s));
@@ -653,6 +655,22 @@ extern "C" int icp_bench_grid_query(icp_ctx *ctx, const double *src, int64_t n, 
     ICP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    // the two kernels of one search separately (events between the launches)
+    double ms_lane = 0.0, ms_defer = 0.0;
+    for (int k = 0; k < 3; ++k) ICP_HIP_CHECK(hipEventCreate(&ev[k]));
+    for (int r = 0; r < reps; ++r) {
+        g_grid_events = ev;
+        const int rc = grid_query(ctx, grid, q, n, nullptr, false, nullptr, idx, nullptr, nullptr);
+        g_grid_events = nullptr;
+        if (rc) return rc;
+        ICP_HIP_CHECK(hipEventSynchronize(ev[2]));
+        float a = 0.f, b2 = 0.f;
+        ICP_HIP_CHECK(hipEventElapsedTime(&a, ev[0], ev[1]));
+        ICP_HIP_CHECK(hipEventElapsedTime(&b2, ev[1], ev[2]));
+        ms_lane += a;
+        ms_defer += b2;
+    }
+    for (int k = 0; k < 3; ++k) (void)hipEventDestroy(ev[k]);
     if (const char *dpath = getenv("ICP_GRID_DEBUG")) {
         long long *d = nullptr;
         ICP_HIP_CHECK(hipMalloc((void **)&d, (size_t)n * 3 * sizeof(long long)));
@@ -668,8 +686,8 @@ extern "C" int icp_bench_grid_query(icp_ctx *ctx, const double *src, int64_t n, 
             fclose(f);
         }
     }
-    const double avg = (double)ms / reps;
-    ICP_HIP_CHECK(hipMemcpyAsync(ms_out_dev, &avg, sizeof(double), hipMemcpyHostToDevice, s));
+    const double avg[3] = {(double)ms / reps, ms_lane / reps, ms_defer / reps};
+    ICP_HIP_CHECK(hipMemcpyAsync(ms_out_dev, avg, sizeof(avg), hipMemcpyHostToDevice, s));
     ICP_HIP_CHECK(hipStreamSynchronize(s));
     return ICP_OK;
 }

@@ -109,14 +109,15 @@ def rigid_icp(source, target, tol, run, use_tol=True, compare_sqrt=False, force_
     return out
 
 
-def time_grid_query(source, target, reps=5, ctx=None):
-    """Average duration (s) of one grid_query_kernel launch as it runs inside icp_rigid_run:
-    target grid prebuilt, queries in Morton order.  Measured with HIP events on the launch
-    stream (bench.py's roofline leg)."""
+def time_grid_query(source, target, reps=5, ctx=None, parts=False):
+    """Average duration (s) of one grid search as it runs inside icp_rigid_run: target grid
+    prebuilt, queries in Morton order.  Measured with HIP events on the launch stream
+    (bench.py's roofline leg).  parts=True: (whole search, grid_query_kernel, grid_defer_kernel)."""
     ctx = ctx or get_context()
     torch = ctx.torch
     src, tgt, dim = _dims(ctx, source, target)
-    ms = ctx.empty((1,))
+    ms = ctx.empty((3,))
     ctx.call("icp_bench_grid_query", ptr(src), src.shape[0], ptr(tgt), tgt.shape[0], dim, int(reps), ptr(ms))
     torch.cuda.synchronize()
-    return float(ms.cpu()[0]) * 1e-3
+    t = [float(x) * 1e-3 for x in ms.cpu()]
+    return tuple(t) if parts else t[0]

@@ -143,9 +143,10 @@ int icp_shard_apply_err(icp_ctx *ctx, const double *src, const double *tgt, cons
 int icp_column_sums(icp_ctx *ctx, const double *a, int64_t n, int dim, double *out_dev);
 
 /* Measurement hook (no counterpart in the reference): builds the target grid and the Morton
- * order of the queries exactly as icp_rigid_run does, then times `reps` launches of the grid
- * search kernel alone with HIP events on the context's stream; ms_out_dev[0] = average
- * milliseconds per launch.  Synchronises. */
+ * order of the queries exactly as icp_rigid_run does, then times `reps` grid searches with HIP
+ * events on the context's stream.  ms_out_dev[3] = average milliseconds of {one whole search,
+ * its per-lane kernel (grid_query_kernel), its wave-per-query kernel for the deferred queries
+ * (grid_defer_kernel)}.  Synchronises. */
 int icp_bench_grid_query(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
                          int reps, double *ms_out_dev);
 
