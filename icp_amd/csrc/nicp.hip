@@ -35,6 +35,10 @@ struct nicp_graph {
     int32_t *rev_ent = nullptr;  // [n*k]
     int32_t *inc_ptr = nullptr;  // [n+1]  incident edges: entries e*2+end
     int32_t *inc_ent = nullptr;  // [2e]
+    // the same adjacencies flattened for the J^T gather (one dependent load less per entry)
+    int32_t *rev_i = nullptr;      // [n*k] row vertex i of entry rev_ent[.]
+    double *rev_w = nullptr;       // [n*k] its weight wt[rev_ent[.]]
+    int32_t *inc_other = nullptr;  // [2e]  the edge's other endpoint
     // solver workspace (grow-once)
     double *ws = nullptr;
     size_t ws_doubles = 0;
@@ -316,18 +320,34 @@ __global__ __launch_bounds__(NB) void jp_kernel(const double *__restrict__ P, co
             vi[c] = v[t * DIM + c];
             acc[c] = 0.0;
         }
-        for (int k = 0; k < K; ++k) {
-            const double w = wt[t * K + k];
-            if (w == 0.0) continue;
-            const int64_t j = nbr[t * K + k];
-            const double *pj = p + j * S;
-            const double wb = (DIM == 2 && COMPAT) ? 1.0 : w;  // Q7
+        for (int k0 = 0; k0 < K; k0 += 4) {  // four neighbours per batch: all gathers issued before use
+            int32_t jj[4];
+            double ww[4], pj[4][S], vn[4][DIM];
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) {
-                double a = 0.0;
+            for (int b4 = 0; b4 < 4; ++b4) {
+                const int kk = k0 + b4 < K ? k0 + b4 : K - 1;
+                jj[b4] = nbr[t * K + kk];
+                ww[b4] = k0 + b4 < K ? wt[t * K + kk] : 0.0;
+            }
 #pragma unroll
-                for (int r = 0; r < DIM; ++r) a += (vi[r] - v[j * DIM + r]) * pj[r * DIM + c];
-                acc[c] += w * a + wb * pj[DIM * DIM + c];
+            for (int b4 = 0; b4 < 4; ++b4) {
+#pragma unroll
+                for (int e = 0; e < S; ++e) pj[b4][e] = p[(int64_t)jj[b4] * S + e];
+#pragma unroll
+                for (int r = 0; r < DIM; ++r) vn[b4][r] = v[(int64_t)jj[b4] * DIM + r];
+            }
+#pragma unroll
+            for (int b4 = 0; b4 < 4; ++b4) {
+                const double w = ww[b4];
+                if (w == 0.0) continue;
+                const double wb = (DIM == 2 && COMPAT) ? 1.0 : w;  // Q7
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int r = 0; r < DIM; ++r) a += (vi[r] - vn[b4][r]) * pj[b4][r * DIM + c];
+                    acc[c] += w * a + wb * pj[b4][DIM * DIM + c];
+                }
             }
         }
 #pragma unroll
@@ -404,8 +424,9 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
                                                 const int32_t *__restrict__ nbr, const double *__restrict__ wt, int K,
                                                 const double *__restrict__ v, const double *__restrict__ rs,
                                                 const int32_t *__restrict__ edges, const int32_t *__restrict__ rev_ptr,
-                                                const int32_t *__restrict__ rev_ent, const int32_t *__restrict__ inc_ptr,
-                                                const int32_t *__restrict__ inc_ent, int64_t n, int64_t ne,
+                                                const int32_t *__restrict__ rev_i, const double *__restrict__ rev_w,
+                                                const int32_t *__restrict__ inc_ptr, const int32_t *__restrict__ inc_ent,
+                                                const int32_t *__restrict__ inc_other, int64_t n, int64_t ne,
                                                 const Globals *__restrict__ g, double c_fit, double c_rigid,
                                                 double c_smooth, const double *__restrict__ lam_d2,
                                                 const double *__restrict__ p_in, double lam, double *__restrict__ out,
@@ -425,32 +446,56 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
 #pragma unroll
             for (int c = 0; c < DIM; ++c) gA[r][c] = 0.0;
         }
-        // fit rows that reference vertex j
-        for (int32_t e = rev_ptr[j]; e < rev_ptr[j + 1]; ++e) {
-            const int32_t ent = rev_ent[e];
-            const int64_t i = ent / K;
-            const double w = wt[ent];
-            if (w == 0.0) continue;
-            const double wb = (DIM == 2 && COMPAT) ? 1.0 : w;
-            double yv[DIM];
+        // fit rows that reference vertex j.  Entries are taken four at a time with every load of
+        // the batch issued before the first use (the chain ptr -> entry -> u/v would otherwise be
+        // paid once per entry); the accumulation order stays ascending, padded slots add 0.
+        {
+            double Rm[DIM][DIM];
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) {
-                double a = 0.0;
+            for (int c = 0; c < DIM; ++c)
 #pragma unroll
-                for (int o = 0; o < DIM; ++o) {
-                    const double Rco = g->R[c * DIM + o];
-                    a += SQUARE ? Rco * Rco : Rco * u[i * DIM + o];
+                for (int o = 0; o < DIM; ++o) Rm[c][o] = g->R[c * DIM + o];
+            const int32_t e_beg = rev_ptr[j], e_end = rev_ptr[j + 1];
+            for (int32_t e0 = e_beg; e0 < e_end; e0 += 4) {
+                int32_t ii[4];
+                double ww[4], uu[4][DIM], vv[4][DIM];
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4) {
+                    const int32_t ee = e0 + b4 < e_end ? e0 + b4 : e_end - 1;
+                    ii[b4] = rev_i[ee];
+                    ww[b4] = e0 + b4 < e_end ? rev_w[ee] : 0.0;
                 }
-                yv[c] = a;
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4)
+#pragma unroll
+                    for (int o = 0; o < DIM; ++o) {
+                        uu[b4][o] = SQUARE ? 0.0 : u[(int64_t)ii[b4] * DIM + o];
+                        vv[b4][o] = v[(int64_t)ii[b4] * DIM + o];
+                    }
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4) {
+                    const double w = ww[b4];
+                    if (w == 0.0) continue;
+                    const double wb = (DIM == 2 && COMPAT) ? 1.0 : w;
+                    double yv[DIM];
+#pragma unroll
+                    for (int c = 0; c < DIM; ++c) {
+                        double a = 0.0;
+#pragma unroll
+                        for (int o = 0; o < DIM; ++o) a += SQUARE ? Rm[c][o] * Rm[c][o] : Rm[c][o] * uu[b4][o];
+                        yv[c] = a;
+                    }
+#pragma unroll
+                    for (int r = 0; r < DIM; ++r) {
+                        const double d = vv[b4][r] - vj[r];
+#pragma unroll
+                        for (int c = 0; c < DIM; ++c)
+                            gA[r][c] += SQUARE ? (c_fit * w * d) * (c_fit * w * d) * yv[c] : -c_fit * w * d * yv[c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < DIM; ++c) gb[c] += SQUARE ? (c_fit * wb) * (c_fit * wb) * yv[c] : -c_fit * wb * yv[c];
+                }
             }
-#pragma unroll
-            for (int r = 0; r < DIM; ++r) {
-                const double d = v[i * DIM + r] - vj[r];
-#pragma unroll
-                for (int c = 0; c < DIM; ++c) gA[r][c] += SQUARE ? (c_fit * w * d) * (c_fit * w * d) * yv[c] : -c_fit * w * d * yv[c];
-            }
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) gb[c] += SQUARE ? (c_fit * wb) * (c_fit * wb) * yv[c] : -c_fit * wb * yv[c];
         }
         // rigid rows of vertex j
         const double *A = P + j * S;
@@ -481,24 +526,43 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
                 }
             }
         }
-        // smooth rows of the edges incident to vertex j
-        for (int32_t e = inc_ptr[j]; e < inc_ptr[j + 1]; ++e) {
-            const int32_t ent = inc_ent[e];
-            const int64_t ed = ent >> 1;
-            const int end = ent & 1;
-            const int64_t p1 = edges[ed * 2], p2 = edges[ed * 2 + 1];
-            const double *us = u_sm + ed * 2 * DIM;
+        // smooth rows of the edges incident to vertex j, four per batch (same scheme).  With the other
+        // endpoint stored per entry, d = v[p2] - v[p1] is (v[other] - vj) at end 0 and (vj - v[other]) at end 1.
+        {
+            const int32_t e_beg = inc_ptr[j], e_end = inc_ptr[j + 1];
+            for (int32_t e0 = e_beg; e0 < e_end; e0 += 4) {
+                int32_t ent[4], oth[4];
+                double us[4][2 * DIM], vo[4][DIM];
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) {
-                const double u0 = SQUARE ? 1.0 : us[c], u1 = SQUARE ? 1.0 : us[DIM + c];
-#pragma unroll
-                for (int r = 0; r < DIM; ++r) {
-                    const double d = v[p2 * DIM + r] - v[p1 * DIM + r];
-                    if (SQUARE) gA[r][c] += c_smooth * c_smooth * d * d;
-                    else gA[r][c] += end == 0 ? c_smooth * d * u0 : -c_smooth * d * u1;
+                for (int b4 = 0; b4 < 4; ++b4) {
+                    const int32_t ee = e0 + b4 < e_end ? e0 + b4 : e_end - 1;
+                    ent[b4] = inc_ent[ee];
+                    oth[b4] = inc_other[ee];
                 }
-                if (SQUARE) gb[c] += 2 * c_smooth * c_smooth;
-                else gb[c] += end == 0 ? c_smooth * (u0 - u1) : c_smooth * (u1 - u0);
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4) {
+#pragma unroll
+                    for (int o = 0; o < DIM; ++o) vo[b4][o] = v[(int64_t)oth[b4] * DIM + o];
+#pragma unroll
+                    for (int o = 0; o < 2 * DIM; ++o) us[b4][o] = SQUARE ? 1.0 : u_sm[(int64_t)(ent[b4] >> 1) * 2 * DIM + o];
+                }
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4) {
+                    if (e0 + b4 >= e_end) continue;
+                    const int end = ent[b4] & 1;
+#pragma unroll
+                    for (int c = 0; c < DIM; ++c) {
+                        const double u0 = us[b4][c], u1 = us[b4][DIM + c];
+#pragma unroll
+                        for (int r = 0; r < DIM; ++r) {
+                            const double d = end == 0 ? vo[b4][r] - vj[r] : vj[r] - vo[b4][r];
+                            if (SQUARE) gA[r][c] += c_smooth * c_smooth * d * d;
+                            else gA[r][c] += end == 0 ? c_smooth * d * u0 : -c_smooth * d * u1;
+                        }
+                        if (SQUARE) gb[c] += 2 * c_smooth * c_smooth;
+                        else gb[c] += end == 0 ? c_smooth * (u0 - u1) : c_smooth * (u1 - u0);
+                    }
+                }
             }
         }
         double pap = 0.0;
@@ -719,7 +783,7 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
                                                        double c_smooth, const double *__restrict__ col2,
                                                        const double *__restrict__ d2, double lam,
                                                        double *__restrict__ binv, Coarse *__restrict__ coarse) {
-    constexpr int S = Lay<DIM>::S, NA = Lay<DIM>::NA, NG = Lay<DIM>::NG, TRI = S * (S + 1) / 2;
+    constexpr int S = Lay<DIM>::S, NA = Lay<DIM>::NA, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (j == 0)
         for (int k = 0; k < NG; ++k) coarse->tail_minv[k] = 1.0 / (col2[n * S + k] + lam * d2[n * S + k]);
@@ -821,11 +885,12 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
                 L[a][b] = sum / L[b][b];
             }
         }
-    double *out = binv + j * TRI;
+    // packed lower triangle, entry q of vertex j at binv[q*n + j] (coalesced for the per-vertex lanes)
+    double *out = binv + j;
     if (!ok) {
         int q = 0;
         for (int a = 0; a < S; ++a)
-            for (int b = 0; b <= a; ++b) out[q++] = a == b ? 1.0 / B[a][a] : 0.0;
+            for (int b = 0; b <= a; ++b) out[(int64_t)(q++) * n] = a == b ? 1.0 / B[a][a] : 0.0;
         return;
     }
     double Li[S][S];  // inverse of L (lower)
@@ -844,7 +909,7 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
         for (int b = 0; b <= a; ++b) {
             double sum = 0.0;
             for (int k = a; k < S; ++k) sum += Li[k][a] * Li[k][b];
-            out[q++] = sum;
+            out[(int64_t)(q++) * n] = sum;
         }
 }
 
@@ -1019,7 +1084,7 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(const Scal *__restri
                                                            double *__restrict__ zb, const double *__restrict__ p,
                                                            const double *__restrict__ Ap, const double *__restrict__ binv,
                                                            double *__restrict__ partial, int64_t nown) {
-    constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG, TRI = S * (S + 1) / 2;
+    constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
     double acc[2 + NG];
     for (int k = 0; k < 2 + NG; ++k) acc[k] = 0.0;
@@ -1032,11 +1097,11 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(const Scal *__restri
             r[j * S + e] = rj[e];
             zj[e] = 0.0;
         }
-        const double *B = binv + j * TRI;
+        const double *B = binv + j;
         int q = 0;
         for (int a = 0; a < S; ++a)
             for (int b = 0; b <= a; ++b) {
-                const double m = B[q++];
+                const double m = B[(int64_t)(q++) * n];
                 zj[a] += m * rj[b];
                 if (a != b) zj[b] += m * rj[a];
             }
@@ -1276,12 +1341,12 @@ static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const 
     if (square) {
         NICP_DISPATCH(g->dim, compat,
                       hipLaunchKernelGGL((jtu_kernel<D, C, true>), dim3(nbk), dim3(NB), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,
-                                         rs, g->edges, g->rev_ptr, g->rev_ent, g->inc_ptr, g->inc_ent, g->n, g->e, w.glob,
+                                         rs, g->edges, g->rev_ptr, g->rev_i, g->rev_w, g->inc_ptr, g->inc_ent, g->inc_other, g->n, g->e, w.glob,
                                          c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial, par.nown));
     } else {
         NICP_DISPATCH(g->dim, compat,
                       hipLaunchKernelGGL((jtu_kernel<D, C, false>), dim3(nbk), dim3(NB), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,
-                                         rs, g->edges, g->rev_ptr, g->rev_ent, g->inc_ptr, g->inc_ent, g->n, g->e, w.glob,
+                                         rs, g->edges, g->rev_ptr, g->rev_i, g->rev_w, g->inc_ptr, g->inc_ent, g->inc_other, g->n, g->e, w.glob,
                                          c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial, par.nown));
     }
     ICP_HIP_CHECK(hipGetLastError());
@@ -1405,7 +1470,7 @@ extern "C" int nicp_graph_destroy(icp_ctx *ctx, nicp_graph *g) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    void *ptrs[] = {g->nbr, g->wt, g->edges, g->rev_ptr, g->rev_ent, g->inc_ptr, g->inc_ent, g->ws};
+    void *ptrs[] = {g->nbr, g->wt, g->edges, g->rev_ptr, g->rev_ent, g->inc_ptr, g->inc_ent, g->rev_i, g->rev_w, g->inc_other, g->ws};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -1421,7 +1486,9 @@ extern "C" int nicp_graph_create(icp_ctx *ctx, const int32_t *nbr_dev, const dou
     ICP_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     std::vector<int32_t> nbr((size_t)n * num_nn), edges((size_t)e * 2);
+    std::vector<double> wth((size_t)n * num_nn);
     ICP_HIP_CHECK(hipMemcpyAsync(nbr.data(), nbr_dev, nbr.size() * 4, hipMemcpyDeviceToHost, st));
+    ICP_HIP_CHECK(hipMemcpyAsync(wth.data(), wt_dev, wth.size() * 8, hipMemcpyDeviceToHost, st));
     if (e) ICP_HIP_CHECK(hipMemcpyAsync(edges.data(), edges_dev, edges.size() * 4, hipMemcpyDeviceToHost, st));
     ICP_HIP_CHECK(hipStreamSynchronize(st));
     for (int32_t x : nbr) ICP_REQUIRE(x >= 0 && x < n, "neighbour index out of range");
@@ -1440,6 +1507,13 @@ extern "C" int nicp_graph_create(icp_ctx *ctx, const int32_t *nbr_dev, const dou
         std::vector<int32_t> cur(inc_ptr.begin(), inc_ptr.end() - 1);
         for (size_t t = 0; t < edges.size(); ++t) inc_ent[cur[edges[t]]++] = (int32_t)t;  // t = e*2+end
     }
+    std::vector<int32_t> rev_i(rev_ent.size()), inc_other(inc_ent.size());
+    std::vector<double> rev_w(rev_ent.size());
+    for (size_t t = 0; t < rev_ent.size(); ++t) {
+        rev_i[t] = rev_ent[t] / num_nn;
+        rev_w[t] = wth[rev_ent[t]];
+    }
+    for (size_t t = 0; t < inc_ent.size(); ++t) inc_other[t] = edges[(size_t)inc_ent[t] ^ 1];  // entry ed*2+end -> ed*2+(1-end)
     nicp_graph *g = new nicp_graph();
     g->n = n;
     g->e = e;
@@ -1459,6 +1533,9 @@ extern "C" int nicp_graph_create(icp_ctx *ctx, const int32_t *nbr_dev, const dou
     if (!rc) rc = up((void **)&g->rev_ent, rev_ent.data(), rev_ent.size() * 4);
     if (!rc) rc = up((void **)&g->inc_ptr, inc_ptr.data(), inc_ptr.size() * 4);
     if (!rc) rc = up((void **)&g->inc_ent, inc_ent.data(), inc_ent.size() * 4);
+    if (!rc) rc = up((void **)&g->rev_i, rev_i.data(), rev_i.size() * 4);
+    if (!rc) rc = up((void **)&g->rev_w, rev_w.data(), rev_w.size() * 8);
+    if (!rc) rc = up((void **)&g->inc_other, inc_other.data(), inc_other.size() * 4);
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = ICP_ERR_HIP;
     if (rc) {
         set_error("nicp_graph_create: device allocation / upload failed");

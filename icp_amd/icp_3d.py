@@ -4,9 +4,10 @@ by libicp_hip.so on an MI355X.
 
 numpy in -> numpy out (like the reference).  torch CUDA tensors in -> CUDA tensors
 out, with no host round trip (use that form to keep clouds resident in HBM).
-The Maya glue of the reference (GetModel, GetVertices, ArrayToMMatrix, the `icp`
-command class; icp_3d.py:16-34,126-207) is host-application code and not part of
-this package.
+The mesh glue of the reference (GetModel, GetVertices, ArrayToMMatrix; icp_3d.py:16-34,
+126-131) is in icp_amd.meshio under the same names: Maya DAG paths inside Maya, file
+names (.obj / .npz) elsewhere; `main(src, tgt, out)` below is icp_3d.py:136-158 on files.
+The `icp` MPxCommand class (icp_3d.py:160-207) needs Maya to register and is not built.
 """
 import numpy as np
 
@@ -69,3 +70,34 @@ def ICP(source, target, tol, run):
     for i, e in enumerate(r["err_hist"].cpu().numpy()[:n]):
         print("err = %f (%2d)" % (e, i))
     return _out(r["T"], as_np)
+
+
+def main(srcPath=None, tgtPath=None, out=None, tol=0.10, run=50):
+    """icp_3d.py:136-158 with files in place of the Maya selection: loads both meshes, runs
+    ICP(src, tgt, 0.10, 50), and (where the reference multiplies the transform node by the
+    result) writes the moved source to `out`.  Returns the 4x4 transform."""
+    from . import meshio
+    print("ICP - Iterative Closest Point")
+    sel = meshio.GetModel(*([srcPath, tgtPath] if srcPath is not None else []))
+    if sel is None:
+        print("You must select 2 models")
+        return None
+    srcPath, tgtPath = sel
+    print("Source model is %s" % srcPath)
+    print("Target model is %s" % tgtPath)
+    srcPts = meshio.GetVertices(srcPath)
+    tgtPts = meshio.GetVertices(tgtPath)
+    print("Source mode has %d vertices" % srcPts.shape[0])
+    print("Target mode has %d vertices" % tgtPts.shape[0])
+    Trans = ICP(srcPts, tgtPts, tol, run)
+    meshio.ArrayToMMatrix(Trans)
+    if out is not None and meshio._is_file(srcPath):
+        meshio.ModifyVertices(srcPath, meshio.apply_matrix(srcPts, Trans), out=out)
+    return Trans
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) < 3:
+        raise SystemExit("usage: python -m icp_amd.icp_3d SRC.obj TGT.obj [OUT.obj]")
+    print(main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None))

@@ -1,0 +1,181 @@
+"""The step either side of the hot path: getting
+`[N,3]` vertices and `[E,2]` edges in, and deformed vertices / the 4x4 transform out.
+
+The reference does this through Maya (`GetModel(s)`, `GetVertices`, `GetVerticesEdges`,
+`ModifyVertices`, `ArrayToMMatrix`: icp_3d.py:16-34,126-131; nicp_3d.py:25-47,368-385;
+nicp3d.cpp:169-177,230-253,424-431).  The same five names are kept here.  A "path" is
+either a Maya `MDagPath` -- then the calls go to `maya.api.OpenMaya` exactly as the
+reference's do, which needs a Maya interpreter -- or a file name (`.obj`, `.npz`), which
+is how the path is driven everywhere else.  Pure host code: no GPU, no libicp_hip.
+
+OBJ subset: `v x y z`, `f a b c ...` (also `a/b/c` tokens, negative indices), `l a b ...`;
+edges are the unique undirected polygon sides in order of first appearance, the same rule
+as `loadObj` of icp_amd/csrc/nicp3d_core.cpp (Maya's own edge numbering is not
+recoverable from a file; NICP's energy does not depend on the edge order).
+"""
+import os
+
+import numpy as np
+
+
+def _maya():
+    try:
+        import maya.api.OpenMaya as om   # only inside Maya
+        return om
+    except Exception:
+        return None
+
+
+def _is_file(path):
+    return isinstance(path, (str, bytes, os.PathLike))
+
+
+# --------------------------------------------------------------------------- files
+def load_obj(path):
+    """(vertices [N,3] float64, edges [E,2] int32) of a Wavefront OBJ."""
+    verts, order, seen = [], [], set()
+
+    def add_edge(a, b):
+        if a == b:
+            return
+        k = (a, b) if a < b else (b, a)
+        if k not in seen:
+            seen.add(k)
+            order.append(k)
+
+    with open(path, "r") as f:
+        for line in f:
+            tok = line.split()
+            if not tok:
+                continue
+            if tok[0] == "v" and len(tok) >= 4:
+                verts.append((float(tok[1]), float(tok[2]), float(tok[3])))
+            elif tok[0] in ("f", "l"):
+                ids = []
+                for t in tok[1:]:
+                    i = int(t.split("/")[0])
+                    ids.append(i - 1 if i > 0 else len(verts) + i)
+                for a, b in zip(ids[:-1], ids[1:]):
+                    add_edge(a, b)
+                if tok[0] == "f" and len(ids) > 2:
+                    add_edge(ids[-1], ids[0])
+    v = np.asarray(verts, dtype=np.float64).reshape(-1, 3)
+    e = np.asarray(order, dtype=np.int32).reshape(-1, 2)
+    if len(e) and (e.min() < 0 or e.max() >= len(v)):
+        raise ValueError("%s: face index outside the vertex list" % path)
+    return v, e
+
+
+def save_obj(path, vertices, template=None):
+    """Write vertices; with `template` (an OBJ path) every non-vertex line of it is kept, so
+    faces / groups / materials survive and only the positions change (what
+    `ModifyVertices` does to a Maya mesh, nicp_3d.py:378-385)."""
+    vertices = np.asarray(vertices, dtype=np.float64)
+    lines = ["v %.17g %.17g %.17g\n" % tuple(p) for p in vertices]
+    if template is None:
+        with open(path, "w") as f:
+            f.writelines(lines)
+        return
+    out, k = [], 0
+    with open(template, "r") as f:
+        for line in f:
+            if line.split()[:1] == ["v"]:
+                if k >= len(lines):
+                    raise ValueError("template has more vertices than the array")
+                out.append(lines[k])
+                k += 1
+            else:
+                out.append(line)
+    if k != len(lines):
+        raise ValueError("template has %d vertices, array has %d" % (k, len(lines)))
+    with open(path, "w") as f:
+        f.writelines(out)
+
+
+def load_npz(path):
+    d = np.load(path)     # allow_pickle stays False
+    v = np.asarray(d["vertices"], dtype=np.float64)
+    e = np.asarray(d["edges"], dtype=np.int32).reshape(-1, 2) if "edges" in d.files else np.zeros((0, 2), np.int32)
+    return v, e
+
+
+def _load(path):
+    p = os.fspath(path)
+    if isinstance(p, bytes):
+        p = p.decode()
+    if p.lower().endswith(".npz"):
+        return load_npz(p)
+    return load_obj(p)
+
+
+# --------------------------------------------------------------------------- the reference's names
+def GetModel(*paths):
+    """icp_3d.py:16-21.  Inside Maya with no arguments: the two selected DAG paths (or None).
+    Elsewhere: the two file names given."""
+    om = _maya()
+    if not paths and om is not None:
+        sel = om.MGlobal.getActiveSelectionList()
+        if sel.length() != 2:
+            return None
+        return sel.getDagPath(0), sel.getDagPath(1)
+    if len(paths) != 2:
+        return None
+    return paths[0], paths[1]
+
+
+def GetVertices(path):
+    """icp_3d.py:26-34: the mesh's points as [N,3] float64."""
+    if _is_file(path):
+        return _load(path)[0]
+    om = _maya()
+    pts = om.MFnMesh(path).getPoints(om.MSpace.kWorld)
+    return np.array([[p.x, p.y, p.z] for p in pts], dtype=np.float64).reshape(-1, 3)
+
+
+def GetVerticesEdges(path):
+    """nicp_3d.py:35-47: (v [N,3], e [E,2]).  The reference returns the edge table as floats
+    (Q11); so does this, the consumers cast it."""
+    if _is_file(path):
+        v, e = _load(path)
+        return v, e.astype(np.float64)
+    om = _maya()
+    mesh = om.MFnMesh(path)
+    pts = mesh.getPoints(om.MSpace.kWorld)
+    v = np.array([[p.x, p.y, p.z] for p in pts], dtype=np.float64).reshape(-1, 3)
+    e = np.array([mesh.getEdgeVertices(i) for i in range(mesh.numEdges)], dtype=np.float64).reshape(-1, 2)
+    return v, e
+
+
+def ModifyVertices(path, dset, out=None):
+    """nicp_3d.py:378-385: move the mesh's points to dset.  For a file, writes `out` (default:
+    overwrite `path`) keeping the faces of the original."""
+    dset = np.asarray(dset.cpu() if hasattr(dset, "is_cuda") else dset, dtype=np.float64)
+    if _is_file(path):
+        p = os.fspath(path)
+        if p.lower().endswith(".npz"):
+            v, e = load_npz(p)
+            np.savez(out or p, vertices=dset, edges=e)
+        else:
+            tmp = (out or p) + ".tmp"
+            save_obj(tmp, dset, template=p)
+            os.replace(tmp, out or p)
+        return
+    om = _maya()
+    om.MFnMesh(path).setPoints([om.MPoint(*row) for row in dset], om.MSpace.kWorld)
+
+
+def ArrayToMMatrix(arr):
+    """icp_3d.py:126-131: the 4x4 row-vector transform as an MMatrix inside Maya, else as the
+    same nested tuple MMatrix is built from."""
+    arr = np.asarray(arr.cpu() if hasattr(arr, "is_cuda") else arr, dtype=np.float64)
+    rows = tuple(tuple(float(arr[r, c]) for c in range(4)) for r in range(4))
+    om = _maya()
+    return om.MMatrix(rows) if om is not None else rows
+
+
+def apply_matrix(vertices, T):
+    """Row-vector convention of the reference: [x y z 1] . T (what `m*t` does to the
+    transform node in icp_3d.py:153-157)."""
+    v = np.asarray(vertices, dtype=np.float64)
+    T = np.asarray(T, dtype=np.float64)
+    return v @ T[:3, :3] + T[3, :3]

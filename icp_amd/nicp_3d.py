@@ -104,3 +104,36 @@ def NICP(P, w, source, edges, target, tol, run):
         print("{0:2d} error = {1:f} [{2:f},{3:f}]".format(i, err, cr, cs))
     c_fit, c_rigid, c_smooth = c
     return _out(dd, as_np), _out(Pn, as_np)
+
+
+def main(srcPath=None, tgtPath=None, out=None, tol=0.01, run=50):
+    """nicp_3d.py:390-409 with files in place of the Maya selection.  The reference stops after
+    Initialise + Match (its NICP / ModifyVertices calls are commented out, :408-409); with `out`
+    given this runs them and writes the deformed source."""
+    from . import meshio
+    print("NICP - Non-rigid Iterative Closest Point")
+    sel = meshio.GetModel(*([srcPath, tgtPath] if srcPath is not None else []))
+    if sel is None:
+        print("You must select 2 models")
+        return None
+    srcPath, tgtPath = sel
+    print("Source model is {0:s}".format(str(srcPath)))
+    print("Target model is {0:s}".format(str(tgtPath)))
+    srcPts, srcEdges = meshio.GetVerticesEdges(srcPath)
+    tgtPts, tgtEdges = meshio.GetVerticesEdges(tgtPath)
+    print("Source mode has {0:d} vertices, {1:d} edges".format(srcPts.shape[0], srcEdges.shape[0]))
+    print("Target mode has {0:d} vertices, {1:d} edges".format(tgtPts.shape[0], tgtEdges.shape[0]))
+    P0, w = Initialise(srcPts, tgtPts)
+    nn = Match(srcPts, tgtPts)
+    if out is None:
+        return P0, w, nn
+    newPts, P = NICP(P0, w, srcPts, srcEdges, tgtPts, tol, run)
+    meshio.ModifyVertices(srcPath, newPts, out=out)
+    return newPts, P
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) < 3:
+        raise SystemExit("usage: python -m icp_amd.nicp_3d SRC.obj TGT.obj [OUT.obj]")
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)

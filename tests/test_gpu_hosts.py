@@ -92,3 +92,44 @@ def test_nicp_row_rt_module():
         np.testing.assert_allclose(pk, ref[:3], rtol=3e-4, atol=3e-4)
         np.testing.assert_allclose(ek, ref[3], rtol=1e-6, atol=1e-10)
         assert ek <= ref[3] * (1 + 1e-12)
+
+
+def test_icp_3d_main_on_files(tmp_path, capsys):
+    """icp_3d.py:136-158 with files for the Maya selection: the transform equals the oracle's
+    ICP on the same vertices and the written mesh is the source moved by it."""
+    from icp_amd import icp_3d, meshio
+    src, tgt = orc.make_rigid_cloud(1000, seed=0)
+    write_obj(tmp_path / "s.obj", src, [])
+    write_obj(tmp_path / "t.obj", tgt, [])
+    T = icp_3d.main(str(tmp_path / "s.obj"), str(tmp_path / "t.obj"), out=str(tmp_path / "o.obj"))
+    text = capsys.readouterr().out
+    assert "ICP - Iterative Closest Point" in text and "Source mode has 1000 vertices" in text
+    T_o = orc.icp(src, tgt, 0.10, 50)
+    np.testing.assert_allclose(T, T_o, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(meshio.GetVertices(str(tmp_path / "o.obj")), src @ T_o[:3, :3] + T_o[3, :3],
+                               rtol=1e-6, atol=1e-9)
+    assert icp_3d.main(str(tmp_path / "s.obj")) is None      # "You must select 2 models"
+
+
+def test_nicp_3d_main_on_files(tmp_path, capsys):
+    """nicp_3d.py:390-409 on files: Initialise + Match as the reference stops there; with an
+    output path the NICP loop runs and the deformed mesh keeps the connectivity."""
+    from icp_amd import nicp_3d, meshio
+    g = golden("nicp_step_24")
+    v, edges, tgt = g["v"], g["edges"], g["tgt"]
+    write_obj(tmp_path / "s.obj", v, edges)
+    write_obj(tmp_path / "t.obj", tgt, edges)
+    P0, w, nn = nicp_3d.main(str(tmp_path / "s.obj"), str(tmp_path / "t.obj"))
+    text = capsys.readouterr().out
+    assert "Source mode has %d vertices, %d edges" % (len(v), len(edges)) in text
+    np.testing.assert_array_equal(nn, tgt[orc.match_idx(v, tgt)[0]])
+    np.testing.assert_allclose(P0, g["P0"])
+    keep = (nicp_3d.c_fit, nicp_3d.c_rigid, nicp_3d.c_smooth)
+    try:
+        newPts, P = nicp_3d.main(str(tmp_path / "s.obj"), str(tmp_path / "t.obj"), out=str(tmp_path / "o.obj"), run=int(g["nicp_run"]))
+    finally:
+        nicp_3d.c_fit, nicp_3d.c_rigid, nicp_3d.c_smooth = keep
+    v_out, e_out = meshio.GetVerticesEdges(str(tmp_path / "o.obj"))
+    np.testing.assert_array_equal(v_out, newPts)
+    np.testing.assert_array_equal(e_out, edges)
+    np.testing.assert_allclose(newPts, g["nicp_dd"], rtol=1e-4, atol=1e-4)   # the reference's own run (compat mode)
