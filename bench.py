@@ -8,8 +8,8 @@ Workload (config C2): 2^20 source x 2^20 target fp64 point
 tgt = N(0,1)^3 with seed 1, src = ((tgt - shift) Rz(0.3)^T)[perm].  One "step" is one
 full ICP iteration: Match (closest point for every source point) + FindTransform
 (Kabsch) + apply + Distance, inputs resident in HBM.  N>1 shards the SOURCE rows over
-the ranks (target replicated), all-reduces 16+1 doubles per iteration over RCCL and
-reports strong scaling (total work fixed).
+the ranks (target replicated), all-reduces 17 doubles per iteration over RCCL (one
+collective) and reports strong scaling (total work fixed).
 
 Prints ONE JSON line (rank 0).  `value` = closest-point queries/s over whole ICP
 iterations (= N_src * K / time); `icp_iters_per_s` is the same run in iterations.
@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--brute", action="store_true", help="force the brute-force closest-point kernel")
     ap.add_argument("--roofline-brute", action="store_true", help="also time one brute-force launch (adds ~1 s)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses GPU 0 and the all-reduce goes over gloo")
     args = ap.parse_args()
 
     import torch
@@ -75,12 +77,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from icp_amd import rigid, _lib
     from icp_amd._lib import get_context, ptr
@@ -117,11 +124,12 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(K):
-            err = st.step()
+            st.step()
+        err = st.flush_err()          # the last iteration's error (earlier ones ride on the next step's all-reduce)
         barrier()
         dt = time.perf_counter() - t0
         err_last = float(err.cpu()[0])
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.cpu()[0])
         src_d, tgt_d = st.src, st.tgt

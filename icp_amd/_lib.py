@@ -156,6 +156,10 @@ class Context:
         self.use_current_stream()
         check(getattr(self.lib, name)(self.handle, *args))
 
+    def call_fast(self, name, *args):
+        """call() without re-reading torch's current stream (the caller did use_current_stream())."""
+        check(getattr(self.lib, name)(self.handle, *args))
+
     # -- buffers ---------------------------------------------------------
     def to_dev(self, a, dtype=None):
         """numpy array / torch tensor -> contiguous tensor on this device."""

@@ -3,9 +3,9 @@
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Source
 rows are split contiguously, the target is replicated.  Per iteration every rank
 runs the closest-point search on its shard (no communication), then ONE all-reduce
-of 16 doubles (shifted sums for the centroid + cross-covariance), an identical
-redundant 3x3 SVD on every rank (bit-identical inputs -> identical R,t, no
-broadcast), and one all-reduce of the scalar error.  Payloads are <= 128 B, i.e.
+of 17 doubles (16 shifted sums for the centroid + cross-covariance, plus the error of
+the previous iteration) and an identical redundant 3x3 SVD on every rank
+(bit-identical inputs -> identical R,t, no broadcast).  The payload is 136 B, i.e.
 latency-bound; nothing here depends on xGMI bandwidth.
 
 The loop is written against a small `ops` interface so the host logic can be
@@ -36,6 +36,11 @@ class GpuOps:
     def to_dev(self, a):
         return self.ctx.to_dev(a)
 
+    def begin(self):
+        """Once per iteration: hand torch's current stream to the context (the per-call form
+        costs two extra host calls per kernel, which shows at ~100 us per iteration)."""
+        self.ctx.use_current_stream()
+
     def zeros(self, n):
         return self.torch.zeros(n, dtype=self.torch.float64, device="cuda:%d" % self.ctx.device)
 
@@ -62,9 +67,9 @@ class GpuOps:
 
     def closest(self, ss, tgt, idx):
         if getattr(self, "_target", None) is not None:
-            self.ctx.call("icp_closest_target", self._target, ptr(ss), ss.shape[0], self.flags, ptr(idx), ptr(None))
+            self.ctx.call_fast("icp_closest_target", self._target, ptr(ss), ss.shape[0], self.flags, ptr(idx), ptr(None))
         else:
-            self.ctx.call("icp_closest", ptr(ss), ss.shape[0], ptr(tgt), tgt.shape[0], ss.shape[1], self.flags,
+            self.ctx.call_fast("icp_closest", ptr(ss), ss.shape[0], ptr(tgt), tgt.shape[0], ss.shape[1], self.flags,
                           ptr(idx), ptr(None))
 
     def __del__(self):
@@ -79,14 +84,14 @@ class GpuOps:
         return self.torch.empty(n, dtype=self.torch.int32, device="cuda:%d" % self.ctx.device)
 
     def shard_sums(self, src, tgt, idx, cs, ct, out):
-        self.ctx.call("icp_shard_sums", ptr(src), ptr(tgt), ptr(idx), src.shape[0], src.shape[1], ptr(cs), ptr(ct),
+        self.ctx.call_fast("icp_shard_sums", ptr(src), ptr(tgt), ptr(idx), src.shape[0], src.shape[1], ptr(cs), ptr(ct),
                       ptr(out))
 
     def kabsch_solve(self, sums, dim, cs, ct, R, t):
-        self.ctx.call("icp_kabsch_solve", ptr(sums), dim, ptr(cs), ptr(ct), ptr(R), ptr(t))
+        self.ctx.call_fast("icp_kabsch_solve", ptr(sums), dim, ptr(cs), ptr(ct), ptr(R), ptr(t))
 
     def apply_err(self, src, tgt, idx, R, t, ss, err):
-        self.ctx.call("icp_shard_apply_err", ptr(src), ptr(tgt), ptr(idx), src.shape[0], src.shape[1], ptr(R), ptr(t),
+        self.ctx.call_fast("icp_shard_apply_err", ptr(src), ptr(tgt), ptr(idx), src.shape[0], src.shape[1], ptr(R), ptr(t),
                       ptr(ss), ptr(err))
 
 
@@ -131,21 +136,45 @@ class ShardedICP:
         self.ct = ct / float(self.tgt.shape[0])
         self.ss = self.src.clone() if hasattr(self.src, "clone") else self.src.copy()
         self.idx = ops.new_idx(n_loc)
-        self.sums = ops.zeros(16)
+        # one buffer for the per-iteration all-reduce: 16 sums of THIS iteration + the error of the
+        # PREVIOUS one (a single latency-bound collective per iteration instead of two)
+        self.buf = ops.zeros(17)
+        self.sums = self.buf[:16]
+        self.err = self.buf[16:17]
         self.R = ops.zeros(self.dim * self.dim)
         self.t = ops.zeros(self.dim)
-        self.err = ops.zeros(1)
+        self.pending_err = False      # buf[16] holds a local (not yet reduced) error
 
-    def step(self):
-        """One ICP iteration (icp_3d.py:108-114) across all ranks; returns the device
-        scalar holding the global error."""
+    def begin_step(self):
+        """Match + sums + the all-reduce.  Afterwards `self.err` is the GLOBAL error of the
+        previous iteration (if there was one) and `self.sums` the global sums of this one."""
         o = self.ops
+        if hasattr(o, "begin"):
+            o.begin()
         o.closest(self.ss, self.tgt, self.idx)
         o.shard_sums(self.src, self.tgt, self.idx, self.cs, self.ct, self.sums)
-        self.comm.all_reduce_sum(self.sums)
+        self.comm.all_reduce_sum(self.buf)
+        self.pending_err = False
+
+    def finish_step(self):
+        """Kabsch solve (redundant, identical on every rank) + apply + local error."""
+        o = self.ops
         o.kabsch_solve(self.sums, self.dim, self.cs, self.ct, self.R, self.t)
         o.apply_err(self.src, self.tgt, self.idx, self.R, self.t, self.ss, self.err)
-        self.comm.all_reduce_sum(self.err)
+        self.pending_err = True
+
+    def flush_err(self):
+        """All-reduce the error of the last finished iteration (end of a run)."""
+        if self.pending_err:
+            self.comm.all_reduce_sum(self.err)
+            self.pending_err = False
+        return self.err
+
+    def step(self):
+        """One ICP iteration (icp_3d.py:108-114) across all ranks.  The error it leaves in
+        `self.err` is local until the next begin_step() / flush_err() reduces it."""
+        self.begin_step()
+        self.finish_step()
         return self.err
 
     def T(self):
@@ -167,10 +196,19 @@ def sharded_icp(ops, comm, src_shard, tgt, tol, run, use_tol=True):
     st = ShardedICP(ops, comm, src_shard, tgt)
     err = 100000000
     hist = []
-    for _ in range(run):
-        e = err
-        err = float(st.step()[0])
-        hist.append(err)
-        if use_tol and (e - err) < tol:
-            break
+    done = 0
+    while True:
+        # the all-reduce of iteration k also delivers the error of iteration k-1, so the stop test
+        # of icp_3d.py:115-116 is evaluated one Match late and that Match is discarded
+        if done < run:
+            st.begin_step()
+        else:
+            st.flush_err()
+        if done > 0:
+            e, err = err, float(st.err[0])
+            hist.append(err)
+            if (use_tol and (e - err) < tol) or done >= run:
+                break
+        st.finish_step()
+        done += 1
     return st.T(), hist

@@ -78,7 +78,7 @@ def main(srcPath=None, tgtPath=None, out=None, tol=0.10, run=50):
     result) writes the moved source to `out`.  Returns the 4x4 transform."""
     from . import meshio
     print("ICP - Iterative Closest Point")
-    sel = meshio.GetModel(*([srcPath, tgtPath] if srcPath is not None else []))
+    sel = meshio.GetModel(*[p for p in (srcPath, tgtPath) if p is not None])
     if sel is None:
         print("You must select 2 models")
         return None

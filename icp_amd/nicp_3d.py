@@ -112,7 +112,7 @@ def main(srcPath=None, tgtPath=None, out=None, tol=0.01, run=50):
     given this runs them and writes the deformed source."""
     from . import meshio
     print("NICP - Non-rigid Iterative Closest Point")
-    sel = meshio.GetModel(*([srcPath, tgtPath] if srcPath is not None else []))
+    sel = meshio.GetModel(*[p for p in (srcPath, tgtPath) if p is not None])
     if sel is None:
         print("You must select 2 models")
         return None
