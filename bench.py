@@ -79,6 +79,8 @@ def main():
         raise SystemExit("bench.py needs an AMD GPU (no CPU fallback)")
     if args.share_gpu:
         local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(60, exit=True)   # a rehearsal that hangs says where
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:

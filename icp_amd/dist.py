@@ -107,7 +107,13 @@ class Comm:
 
     def all_reduce_sum(self, t):
         if self.enabled:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if getattr(t, "is_cuda", False) and self.dist.get_backend(self.group) != "nccl":
+                # gloo (ranks sharing a GPU, rehearsals): stage through host memory
+                h = t.cpu()
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
 
