@@ -28,6 +28,7 @@
 struct nicp_graph {
     int64_t n = 0, e = 0;
     int dim = 3, k = 4;
+    int vb = 256;                // threads per block of the per-vertex kernels (64 on small meshes: more CUs busy)
     int32_t *nbr = nullptr;      // [n,k]
     double *wt = nullptr;        // [n,k]
     int32_t *edges = nullptr;    // [e,2]
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(NB) void jp_kernel(const double *__restrict__ P, co
                                                const Globals *__restrict__ g, double c_fit, double c_rigid,
                                                double c_smooth, double *__restrict__ y) {
     constexpr int S = Lay<DIM>::S, NRIG = Lay<DIM>::NRIG, NANG = Lay<DIM>::NANG;
-    const int64_t t = (int64_t)blockIdx.x * NB + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double *y_rig = y + n * DIM, *y_sm = y + n * DIM + n * NRIG;
     const double *ptail = p + n * S;
     if (t < n) {
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
                                                 const double *__restrict__ p_in, double lam, double *__restrict__ out,
                                                 double *__restrict__ partial, int64_t nown) {
     constexpr int S = Lay<DIM>::S, NRIG = Lay<DIM>::NRIG, NANG = Lay<DIM>::NANG, NG = Lay<DIM>::NG;
-    const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const double *u_rig = u + n * DIM, *u_sm = u + n * DIM + n * NRIG;
     double gacc[kSumSlots];
 #pragma unroll
@@ -446,124 +447,161 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
 #pragma unroll
             for (int c = 0; c < DIM; ++c) gA[r][c] = 0.0;
         }
-        // fit rows that reference vertex j.  Entries are taken four at a time with every load of
-        // the batch issued before the first use (the chain ptr -> entry -> u/v would otherwise be
-        // paid once per entry); the accumulation order stays ascending, padded slots add 0.
-        {
-            double Rm[DIM][DIM];
+        // The gathers of this kernel form a chain  ptr -> entry -> u / v  per adjacency list.  To pay it
+        // once, not once per entry, entries are taken in batches with every load of a batch issued
+        // before its first use, and the FIRST batch of both lists (4 fit rows, 8 edges: all of them on
+        // ordinary meshes) is fetched up front, side by side.  The accumulation order is unchanged
+        // (fit rows ascending, rigid rows, edges ascending); padded slots add nothing.
+        constexpr int RB = 4, IB = 8;
+        double Rm[DIM][DIM];
 #pragma unroll
-            for (int c = 0; c < DIM; ++c)
+        for (int c = 0; c < DIM; ++c)
 #pragma unroll
-                for (int o = 0; o < DIM; ++o) Rm[c][o] = g->R[c * DIM + o];
-            const int32_t e_beg = rev_ptr[j], e_end = rev_ptr[j + 1];
-            for (int32_t e0 = e_beg; e0 < e_end; e0 += 4) {
-                int32_t ii[4];
-                double ww[4], uu[4][DIM], vv[4][DIM];
+            for (int o = 0; o < DIM; ++o) Rm[c][o] = g->R[c * DIM + o];
+        const int32_t rv_beg = rev_ptr[j], rv_end = rev_ptr[j + 1], in_beg = inc_ptr[j], in_end = inc_ptr[j + 1];
+        const int32_t rv_cl = rv_end > rv_beg ? rv_end - 1 : 0, in_cl = in_end > in_beg ? in_end - 1 : 0;
+
+        auto fit_entries = [&](int32_t e0, int32_t (&ii)[RB], double (&ww)[RB]) {
 #pragma unroll
-                for (int b4 = 0; b4 < 4; ++b4) {
-                    const int32_t ee = e0 + b4 < e_end ? e0 + b4 : e_end - 1;
-                    ii[b4] = rev_i[ee];
-                    ww[b4] = e0 + b4 < e_end ? rev_w[ee] : 0.0;
+            for (int q = 0; q < RB; ++q) {
+                const int32_t ee = e0 + q < rv_end ? e0 + q : rv_cl;
+                ii[q] = rev_i[ee];
+                ww[q] = e0 + q < rv_end ? rev_w[ee] : 0.0;
+            }
+        };
+        auto fit_gather = [&](const int32_t (&ii)[RB], double (&uu)[RB][DIM], double (&vv)[RB][DIM]) {
+#pragma unroll
+            for (int q = 0; q < RB; ++q)
+#pragma unroll
+                for (int o = 0; o < DIM; ++o) {
+                    uu[q][o] = SQUARE ? 0.0 : u[(int64_t)ii[q] * DIM + o];
+                    vv[q][o] = v[(int64_t)ii[q] * DIM + o];
+                }
+        };
+        auto fit_accumulate = [&](const double (&ww)[RB], const double (&uu)[RB][DIM], const double (&vv)[RB][DIM]) {
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const double w = ww[q];
+                if (w == 0.0) continue;
+                const double wb = (DIM == 2 && COMPAT) ? 1.0 : w;
+                double yv[DIM];
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int o = 0; o < DIM; ++o) a += SQUARE ? Rm[c][o] * Rm[c][o] : Rm[c][o] * uu[q][o];
+                    yv[c] = a;
                 }
 #pragma unroll
-                for (int b4 = 0; b4 < 4; ++b4)
+                for (int r = 0; r < DIM; ++r) {
+                    const double d = vv[q][r] - vj[r];
 #pragma unroll
-                    for (int o = 0; o < DIM; ++o) {
-                        uu[b4][o] = SQUARE ? 0.0 : u[(int64_t)ii[b4] * DIM + o];
-                        vv[b4][o] = v[(int64_t)ii[b4] * DIM + o];
-                    }
+                    for (int c = 0; c < DIM; ++c)
+                        gA[r][c] += SQUARE ? (c_fit * w * d) * (c_fit * w * d) * yv[c] : -c_fit * w * d * yv[c];
+                }
 #pragma unroll
-                for (int b4 = 0; b4 < 4; ++b4) {
-                    const double w = ww[b4];
-                    if (w == 0.0) continue;
-                    const double wb = (DIM == 2 && COMPAT) ? 1.0 : w;
-                    double yv[DIM];
+                for (int c = 0; c < DIM; ++c) gb[c] += SQUARE ? (c_fit * wb) * (c_fit * wb) * yv[c] : -c_fit * wb * yv[c];
+            }
+        };
+        // with the other endpoint stored per entry, d = v[p2] - v[p1] is (v[other] - vj) at end 0 and (vj - v[other]) at end 1
+        auto edge_entries = [&](int32_t e0, int32_t (&ent)[IB], int32_t (&oth)[IB]) {
 #pragma unroll
-                    for (int c = 0; c < DIM; ++c) {
-                        double a = 0.0;
+            for (int q = 0; q < IB; ++q) {
+                const int32_t ee = e0 + q < in_end ? e0 + q : in_cl;
+                ent[q] = inc_ent[ee];
+                oth[q] = inc_other[ee];
+            }
+        };
+        auto edge_gather = [&](const int32_t (&ent)[IB], const int32_t (&oth)[IB], double (&us)[IB][2 * DIM], double (&vo)[IB][DIM]) {
 #pragma unroll
-                        for (int o = 0; o < DIM; ++o) a += SQUARE ? Rm[c][o] * Rm[c][o] : Rm[c][o] * uu[b4][o];
-                        yv[c] = a;
-                    }
+            for (int q = 0; q < IB; ++q) {
+#pragma unroll
+                for (int o = 0; o < DIM; ++o) vo[q][o] = v[(int64_t)oth[q] * DIM + o];
+#pragma unroll
+                for (int o = 0; o < 2 * DIM; ++o) us[q][o] = SQUARE ? 1.0 : u_sm[(int64_t)(ent[q] >> 1) * 2 * DIM + o];
+            }
+        };
+        auto edge_accumulate = [&](int32_t e0, const int32_t (&ent)[IB], const double (&us)[IB][2 * DIM], const double (&vo)[IB][DIM]) {
+#pragma unroll
+            for (int q = 0; q < IB; ++q) {
+                if (e0 + q >= in_end) continue;
+                const int end = ent[q] & 1;
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) {
+                    const double u0 = us[q][c], u1 = us[q][DIM + c];
 #pragma unroll
                     for (int r = 0; r < DIM; ++r) {
-                        const double d = vv[b4][r] - vj[r];
-#pragma unroll
-                        for (int c = 0; c < DIM; ++c)
-                            gA[r][c] += SQUARE ? (c_fit * w * d) * (c_fit * w * d) * yv[c] : -c_fit * w * d * yv[c];
+                        const double d = end == 0 ? vo[q][r] - vj[r] : vj[r] - vo[q][r];
+                        if (SQUARE) gA[r][c] += c_smooth * c_smooth * d * d;
+                        else gA[r][c] += end == 0 ? c_smooth * d * u0 : -c_smooth * d * u1;
                     }
-#pragma unroll
-                    for (int c = 0; c < DIM; ++c) gb[c] += SQUARE ? (c_fit * wb) * (c_fit * wb) * yv[c] : -c_fit * wb * yv[c];
+                    if (SQUARE) gb[c] += 2 * c_smooth * c_smooth;
+                    else gb[c] += end == 0 ? c_smooth * (u0 - u1) : c_smooth * (u1 - u0);
                 }
             }
+        };
+
+        // first batches of both lists + the vertex's own rows: entries, then every gather
+        int32_t ii0[RB], ent0[IB], oth0[IB];
+        double ww0[RB], uu0[RB][DIM], vv0[RB][DIM], us0[IB][2 * DIM], vo0[IB][DIM];
+        fit_entries(rv_beg, ii0, ww0);
+        edge_entries(in_beg, ent0, oth0);
+        double Aown[Lay<DIM>::NA], urown[NRIG];
+#pragma unroll
+        for (int e = 0; e < Lay<DIM>::NA; ++e) Aown[e] = P[j * S + e];
+#pragma unroll
+        for (int e = 0; e < NRIG; ++e) urown[e] = SQUARE ? 0.0 : u_rig[j * NRIG + e];
+        fit_gather(ii0, uu0, vv0);
+        edge_gather(ent0, oth0, us0, vo0);
+
+        // fit rows that reference vertex j
+        fit_accumulate(ww0, uu0, vv0);
+        for (int32_t e0 = rv_beg + RB; e0 < rv_end; e0 += RB) {
+            int32_t ii[RB];
+            double ww[RB], uu[RB][DIM], vv[RB][DIM];
+            fit_entries(e0, ii, ww);
+            fit_gather(ii, uu, vv);
+            fit_accumulate(ww, uu, vv);
         }
         // rigid rows of vertex j
-        const double *A = P + j * S;
-        if (DIM == 3) {
-            const double *ur = u_rig + j * 6;
-            for (int c = 0; c < 3; ++c) {
-                const double a0 = A[c], a1 = A[3 + c], a2 = A[6 + c];
-                if (SQUARE) {
-                    gA[0][c] += c_rigid * c_rigid * (a1 * a1 + a2 * a2 + 4 * a0 * a0);
-                    gA[1][c] += c_rigid * c_rigid * (a0 * a0 + a2 * a2 + 4 * a1 * a1);
-                    gA[2][c] += c_rigid * c_rigid * (a1 * a1 + a0 * a0 + 4 * a2 * a2);
-                } else {
-                    gA[0][c] += c_rigid * (ur[0] * a1 + ur[2] * a2 - 2 * ur[3] * a0);
-                    gA[1][c] += c_rigid * (ur[0] * a0 + ur[1] * a2 - 2 * ur[4] * a1);
-                    gA[2][c] += c_rigid * (ur[1] * a1 + ur[2] * a0 - 2 * ur[5] * a2);
-                }
-            }
-        } else {
-            const double *ur = u_rig + j * 3;
-            for (int c = 0; c < 2; ++c) {
-                const double a0 = A[c], a1 = A[2 + c];
-                if (SQUARE) {
-                    gA[0][c] += c_rigid * c_rigid * (a1 * a1 + 4 * a0 * a0);
-                    gA[1][c] += c_rigid * c_rigid * (a0 * a0 + 4 * a1 * a1);
-                } else {
-                    gA[0][c] += c_rigid * (ur[0] * a1 - 2 * ur[1] * a0);
-                    gA[1][c] += c_rigid * (ur[0] * a0 - 2 * ur[2] * a1);
-                }
-            }
-        }
-        // smooth rows of the edges incident to vertex j, four per batch (same scheme).  With the other
-        // endpoint stored per entry, d = v[p2] - v[p1] is (v[other] - vj) at end 0 and (vj - v[other]) at end 1.
         {
-            const int32_t e_beg = inc_ptr[j], e_end = inc_ptr[j + 1];
-            for (int32_t e0 = e_beg; e0 < e_end; e0 += 4) {
-                int32_t ent[4], oth[4];
-                double us[4][2 * DIM], vo[4][DIM];
+            const double *A = Aown, *ur = urown;
+            if (DIM == 3) {
 #pragma unroll
-                for (int b4 = 0; b4 < 4; ++b4) {
-                    const int32_t ee = e0 + b4 < e_end ? e0 + b4 : e_end - 1;
-                    ent[b4] = inc_ent[ee];
-                    oth[b4] = inc_other[ee];
+                for (int c = 0; c < 3; ++c) {
+                    const double a0 = A[c], a1 = A[3 + c], a2 = A[6 + c];
+                    if (SQUARE) {
+                        gA[0][c] += c_rigid * c_rigid * (a1 * a1 + a2 * a2 + 4 * a0 * a0);
+                        gA[1][c] += c_rigid * c_rigid * (a0 * a0 + a2 * a2 + 4 * a1 * a1);
+                        gA[2][c] += c_rigid * c_rigid * (a1 * a1 + a0 * a0 + 4 * a2 * a2);
+                    } else {
+                        gA[0][c] += c_rigid * (ur[0] * a1 + ur[2] * a2 - 2 * ur[3] * a0);
+                        gA[1][c] += c_rigid * (ur[0] * a0 + ur[1] * a2 - 2 * ur[4] * a1);
+                        gA[2][c] += c_rigid * (ur[1] * a1 + ur[2] * a0 - 2 * ur[5] * a2);
+                    }
                 }
+            } else {
 #pragma unroll
-                for (int b4 = 0; b4 < 4; ++b4) {
-#pragma unroll
-                    for (int o = 0; o < DIM; ++o) vo[b4][o] = v[(int64_t)oth[b4] * DIM + o];
-#pragma unroll
-                    for (int o = 0; o < 2 * DIM; ++o) us[b4][o] = SQUARE ? 1.0 : u_sm[(int64_t)(ent[b4] >> 1) * 2 * DIM + o];
-                }
-#pragma unroll
-                for (int b4 = 0; b4 < 4; ++b4) {
-                    if (e0 + b4 >= e_end) continue;
-                    const int end = ent[b4] & 1;
-#pragma unroll
-                    for (int c = 0; c < DIM; ++c) {
-                        const double u0 = us[b4][c], u1 = us[b4][DIM + c];
-#pragma unroll
-                        for (int r = 0; r < DIM; ++r) {
-                            const double d = end == 0 ? vo[b4][r] - vj[r] : vj[r] - vo[b4][r];
-                            if (SQUARE) gA[r][c] += c_smooth * c_smooth * d * d;
-                            else gA[r][c] += end == 0 ? c_smooth * d * u0 : -c_smooth * d * u1;
-                        }
-                        if (SQUARE) gb[c] += 2 * c_smooth * c_smooth;
-                        else gb[c] += end == 0 ? c_smooth * (u0 - u1) : c_smooth * (u1 - u0);
+                for (int c = 0; c < 2; ++c) {
+                    const double a0 = A[c], a1 = A[2 + c];
+                    if (SQUARE) {
+                        gA[0][c] += c_rigid * c_rigid * (a1 * a1 + 4 * a0 * a0);
+                        gA[1][c] += c_rigid * c_rigid * (a0 * a0 + 4 * a1 * a1);
+                    } else {
+                        gA[0][c] += c_rigid * (ur[0] * a1 - 2 * ur[1] * a0);
+                        gA[1][c] += c_rigid * (ur[0] * a0 - 2 * ur[2] * a1);
                     }
                 }
             }
+        }
+        // smooth rows of the edges incident to vertex j
+        edge_accumulate(in_beg, ent0, us0, vo0);
+        for (int32_t e0 = in_beg + IB; e0 < in_end; e0 += IB) {
+            int32_t ent[IB], oth[IB];
+            double us[IB][2 * DIM], vo[IB][DIM];
+            edge_entries(e0, ent, oth);
+            edge_gather(ent, oth, us, vo);
+            edge_accumulate(e0, ent, us, vo);
         }
         double pap = 0.0;
 #pragma unroll
@@ -615,7 +653,7 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
     __syncthreads();
     if (tid < 9 && (tid < NG || tid == 8)) {
         double s = red[0][tid];
-        for (int w = 1; w < NB / 64; ++w) s += red[w][tid];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s += red[w][tid];
         partial[(int64_t)blockIdx.x * kSumSlots + tid] = s;
     }
 }
@@ -918,7 +956,7 @@ template <int DIM>
 __global__ __launch_bounds__(NB) void zcol_kernel(const double *__restrict__ P, const double *__restrict__ v, int64_t n,
                                                  int a, double *__restrict__ out) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
-    const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) {
         double z[NG][S];
         zmodes<DIM>(P + j * S, v + j * DIM, z);
@@ -937,7 +975,7 @@ template <int DIM>
 __global__ __launch_bounds__(NB) void zt_kernel(const double *__restrict__ P, const double *__restrict__ v, int64_t n,
                                                const double *__restrict__ r, double *__restrict__ partial) {  // n = owned vertices
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
-    const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc[NG];
     for (int k = 0; k < NG; ++k) acc[k] = 0.0;
     if (j < n) {
@@ -955,15 +993,15 @@ __global__ __launch_bounds__(NB) void zt_kernel(const double *__restrict__ P, co
     __syncthreads();
     if (tid < NG) {
         double s = red[0][tid];
-        for (int w = 1; w < NB / 64; ++w) s += red[w][tid];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s += red[w][tid];
         partial[(int64_t)blockIdx.x * kSumSlots + tid] = s;
     }
 }
 // tot[off + k] = sum_b partial[b][k] for the slots in `mask`: one wave per slot (single block of 1024).
 // Every reduction below is "block partials -> rows_sum -> [all-reduce over ranks] -> logic kernel", so the
 // sharded solver only inserts the all-reduce; the summation tree is fixed, hence deterministic.
-__global__ __launch_bounds__(1024) void rows_sum_kernel(const double *__restrict__ partial, int nb, unsigned mask,
-                                                        double *__restrict__ tot, int off) {
+__device__ __forceinline__ void block_rows_sum(const double *__restrict__ partial, int nb, unsigned mask,
+                                               double *__restrict__ tot, int off) {
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k < kSumSlots && ((mask >> k) & 1u)) {
         double a = 0.0;
@@ -971,6 +1009,10 @@ __global__ __launch_bounds__(1024) void rows_sum_kernel(const double *__restrict
         a = wave_sum(a);
         if (lane == 0) tot[off + k] = a;
     }
+}
+__global__ __launch_bounds__(1024) void rows_sum_kernel(const double *__restrict__ partial, int nb, unsigned mask,
+                                                        double *__restrict__ tot, int off) {
+    block_rows_sum(partial, nb, mask, tot, off);
 }
 
 // out_tail[k] = tot[off + k] + lam d2_tail[k] p_tail[k]: tail of J^T u (the tail entries are replicated)
@@ -990,11 +1032,10 @@ __global__ void ecol_logic_kernel(const double *__restrict__ tot, int ng, const 
     coarse->E[(ng + k) * nz + a] = tot[8 + k] + lam * d2_tail[k] * ztail;
 }
 
-// after J^T: tail of A p, p.Ap and alpha.  tot[0..ng) tail sums, tot[8] vertex part of p.Ap
-__global__ void cg_alpha_logic_kernel(const double *__restrict__ tot, int ng, const double *__restrict__ d2_tail,
-                                      const double *__restrict__ p_tail, double lam, double *__restrict__ Ap_tail,
-                                      Scal *__restrict__ s) {
-    if (threadIdx.x != 0 || s->stop) return;
+// after J^T: tail of A p, p.Ap and alpha.  tot[0..ng) tail sums, tot[8] vertex part of p.Ap  (one thread)
+__device__ __forceinline__ void alpha_logic(const double *tot, int ng, const double *d2_tail, const double *p_tail, double lam,
+                                            double *Ap_tail, Scal *s) {
+    if (s->stop) return;
     double pap = tot[8];
     for (int k = 0; k < ng; ++k) {
         const double val = tot[k] + lam * d2_tail[k] * p_tail[k];
@@ -1005,12 +1046,25 @@ __global__ void cg_alpha_logic_kernel(const double *__restrict__ tot, int ng, co
     s->alpha = pap > 0 ? s->rz / pap : 0.0;
     if (!(pap > 0)) s->stop = 2;  // breakdown (non-positive curvature / NaN)
 }
+__global__ void cg_alpha_logic_kernel(const double *__restrict__ tot, int ng, const double *__restrict__ d2_tail,
+                                      const double *__restrict__ p_tail, double lam, double *__restrict__ Ap_tail,
+                                      Scal *__restrict__ s) {
+    if (threadIdx.x == 0) alpha_logic(tot, ng, d2_tail, p_tail, lam, Ap_tail, s);
+}
+// single GPU: row sum and logic in one launch (nothing to all-reduce in between)
+__global__ __launch_bounds__(1024) void cg_sum_alpha_kernel(const double *__restrict__ partial, int nb, unsigned mask,
+                                                            double *__restrict__ tot, int ng, const double *__restrict__ d2_tail,
+                                                            const double *__restrict__ p_tail, double lam,
+                                                            double *__restrict__ Ap_tail, Scal *__restrict__ s) {
+    block_rows_sum(partial, nb, mask, tot, 0);
+    __syncthreads();
+    if (threadIdx.x == 0) alpha_logic(tot, ng, d2_tail, p_tail, lam, Ap_tail, s);
+}
 
 // tail update, coarse solve y = Einv Z^T r, r.z, beta, stop test.  tot[0] r.zb, tot[1] r.r, tot[2..2+ng) Z_v^T r
-__global__ __launch_bounds__(64) void cg_coarse_logic_kernel(const double *__restrict__ tot, int ng, double *__restrict__ x_tail,
-                                                            double *__restrict__ r_tail, double *__restrict__ zb_tail,
-                                                            const double *__restrict__ p_tail, const double *__restrict__ Ap_tail,
-                                                            Coarse *__restrict__ coarse, Scal *__restrict__ s, double tol2, int init) {
+__device__ __forceinline__ void coarse_logic(const double *tot, int ng, double *x_tail, double *r_tail, double *zb_tail,
+                                             const double *p_tail, const double *Ap_tail, Coarse *coarse, Scal *s, double tol2,
+                                             int init) {
     const int tid = threadIdx.x;
     const int stop = s->stop;  // uniform: only thread 0 writes it, at the very end
     if (stop) return;
@@ -1058,6 +1112,21 @@ __global__ __launch_bounds__(64) void cg_coarse_logic_kernel(const double *__res
         if (!(rr > tol2 * s->rr0)) s->stop = 1;
     }
 }
+__global__ __launch_bounds__(64) void cg_coarse_logic_kernel(const double *__restrict__ tot, int ng, double *__restrict__ x_tail,
+                                                            double *__restrict__ r_tail, double *__restrict__ zb_tail,
+                                                            const double *__restrict__ p_tail, const double *__restrict__ Ap_tail,
+                                                            Coarse *__restrict__ coarse, Scal *__restrict__ s, double tol2, int init) {
+    coarse_logic(tot, ng, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s, tol2, init);
+}
+__global__ __launch_bounds__(1024) void cg_sum_coarse_kernel(const double *__restrict__ partial, int nb, unsigned mask,
+                                                             double *__restrict__ tot, int ng, double *__restrict__ x_tail,
+                                                             double *__restrict__ r_tail, double *__restrict__ zb_tail,
+                                                             const double *__restrict__ p_tail, const double *__restrict__ Ap_tail,
+                                                             Coarse *__restrict__ coarse, Scal *__restrict__ s, double tol2, int init) {
+    block_rows_sum(partial, nb, mask, tot, 0);
+    __syncthreads();
+    coarse_logic(tot, ng, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s, tol2, init);
+}
 
 // tot[slot] += sum_k a[k] b[k] (w ? w[k] : 1) over the ng replicated tail entries (added on one rank only)
 __global__ void add_tail_dot_kernel(double *__restrict__ tot, int slot, const double *__restrict__ a,
@@ -1085,7 +1154,7 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(const Scal *__restri
                                                            const double *__restrict__ Ap, const double *__restrict__ binv,
                                                            double *__restrict__ partial, int64_t nown) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
-    const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc[2 + NG];
     for (int k = 0; k < 2 + NG; ++k) acc[k] = 0.0;
     if (j < nown && !s->stop) {
@@ -1123,7 +1192,7 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(const Scal *__restri
     __syncthreads();
     if (tid < 2 + NG) {
         double t = red[0][tid];
-        for (int w = 1; w < NB / 64; ++w) t += red[w][tid];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t += red[w][tid];
         partial[(int64_t)blockIdx.x * kSumSlots + tid] = t;
     }
 }
@@ -1135,7 +1204,7 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(const Scal *__restrict_
                                                         const double *__restrict__ zb, double *__restrict__ p, int64_t nown) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
     if (s->stop) return;
-    const int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const double beta = s->beta;
     if (j < n) {
         if (j >= nown) return;  // halo copy
@@ -1152,6 +1221,7 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(const Scal *__restrict_
     }
 }
 
+static inline int vgrid(const nicp_graph *g, int64_t len) { return (int)((len + g->vb - 1) / g->vb); }
 static inline int grid_for(int64_t len, int cap = 1024) {
     int64_t nb = (len + NB - 1) / NB;
     return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
@@ -1268,10 +1338,10 @@ static int residual_at(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, co
 // y = J p at the linearisation held in w (call linearise first)
 static int apply_J(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, const double *v, const double *c, bool compat,
                    const double *p, double *y) {
-    const int nbk = grid_for(g->n + g->e, 1 << 30);
+    const int nbk = vgrid(g, g->n + g->e);
     const double *rs = compat ? w.dd : w.pre;  // Q6
     NICP_DISPATCH(g->dim, compat,
-                  hipLaunchKernelGGL((jp_kernel<D, C>), dim3(nbk), dim3(NB), 0, ctx->stream, P, p, g->nbr, g->wt, g->k, v, rs,
+                  hipLaunchKernelGGL((jp_kernel<D, C>), dim3(nbk), dim3(g->vb), 0, ctx->stream, P, p, g->nbr, g->wt, g->k, v, rs,
                                      g->edges, g->n, g->e, w.glob, c[0], c[1], c[2], y));
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
@@ -1332,7 +1402,7 @@ static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const 
                     bool compat, const double *u, const double *lam_d2, const double *p_in, double lam, double *out,
                     bool square, bool finish_tail = true) {
     const Dims d = dims_of(g);
-    const int nbk = grid_for(g->n, 1 << 30);
+    const int nbk = vgrid(g, g->n);
     const double *rs = compat ? w.dd : w.pre;
     if (nbk > kMaxPartials) {
         set_error("nicp: mesh too large for the partial buffer (%lld vertices)", (long long)g->n);
@@ -1340,12 +1410,12 @@ static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const 
     }
     if (square) {
         NICP_DISPATCH(g->dim, compat,
-                      hipLaunchKernelGGL((jtu_kernel<D, C, true>), dim3(nbk), dim3(NB), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,
+                      hipLaunchKernelGGL((jtu_kernel<D, C, true>), dim3(nbk), dim3(g->vb), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,
                                          rs, g->edges, g->rev_ptr, g->rev_i, g->rev_w, g->inc_ptr, g->inc_ent, g->inc_other, g->n, g->e, w.glob,
                                          c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial, par.nown));
     } else {
         NICP_DISPATCH(g->dim, compat,
-                      hipLaunchKernelGGL((jtu_kernel<D, C, false>), dim3(nbk), dim3(NB), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,
+                      hipLaunchKernelGGL((jtu_kernel<D, C, false>), dim3(nbk), dim3(g->vb), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,
                                          rs, g->edges, g->rev_ptr, g->rev_i, g->rev_w, g->inc_ptr, g->inc_ent, g->inc_other, g->n, g->e, w.glob,
                                          c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial, par.nown));
     }
@@ -1519,6 +1589,7 @@ extern "C" int nicp_graph_create(icp_ctx *ctx, const int32_t *nbr_dev, const dou
     g->e = e;
     g->dim = dim;
     g->k = num_nn;
+    g->vb = n <= 65536 ? 64 : 256;
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
         if (hipMalloc(dst, bytes ? bytes : 8) != hipSuccess) return ICP_ERR_NOMEM;
         if (bytes && hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return ICP_ERR_HIP;
@@ -1630,8 +1701,8 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, doub
             hipLaunchKernelGGL(scaling_kernel, dim3(nbp), dim3(NB), 0, st, w.col2, w.d2, w.minv, lam, first_scaling ? 1 : 0, d.np);
             first_scaling = false;
             // ---- two-level preconditioner for (J^T J + lam D^2): inverted vertex blocks + coarse space
-            const int nbv = (int)((nown + NB - 1) / NB), nbt = (int)((d.n + d.NG + NB - 1) / NB), nz = 2 * d.NG;
-            const int nbj = grid_for(d.n, 1 << 30);  // blocks of the J^T kernel (all local vertices)
+            const int nbv = vgrid(g, nown), nbt = vgrid(g, d.n + d.NG), nz = 2 * d.NG;
+            const int nbj = vgrid(g, d.n);  // blocks of the J^T kernel (all local vertices)
             const unsigned ng_mask = (1u << d.NG) - 1u;
             double *x_tail = w.delta + d.n * d.S, *r_tail = w.rcg + d.n * d.S, *zb_tail = w.z + d.n * d.S;
             double *p_tail = w.pcg + d.n * d.S, *Ap_tail = w.Ap + d.n * d.S;
@@ -1644,13 +1715,13 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, doub
                                              w.binv, w.coarse));
             ICP_HIP_CHECK(hipGetLastError());
             for (int a = 0; a < nz; ++a) {  // E[:, a] = Z^T (J^T J + lam D^2) z_a
-                if (g->dim == 3) hipLaunchKernelGGL(zcol_kernel<3>, dim3(nbt), dim3(NB), 0, st, (const double *)x, v, d.n, a, w.z);
-                else hipLaunchKernelGGL(zcol_kernel<2>, dim3(nbt), dim3(NB), 0, st, (const double *)x, v, d.n, a, w.z);
+                if (g->dim == 3) hipLaunchKernelGGL(zcol_kernel<3>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z);
+                else hipLaunchKernelGGL(zcol_kernel<2>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z);
                 if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.z, w.y)) return rc;
                 if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.y, w.d2, w.z, lam, w.Ap, false, false)) return rc;
                 hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask, par.tot, 8);
-                if (g->dim == 3) hipLaunchKernelGGL(zt_kernel<3>, dim3(nbv), dim3(NB), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial);
-                else hipLaunchKernelGGL(zt_kernel<2>, dim3(nbv), dim3(NB), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial);
+                if (g->dim == 3) hipLaunchKernelGGL(zt_kernel<3>, dim3(nbv), dim3(g->vb), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial);
+                else hipLaunchKernelGGL(zt_kernel<2>, dim3(nbv), dim3(g->vb), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial);
                 hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, ng_mask, par.tot, 0);
                 if (int rc = allreduce(par, 16)) return rc;
                 hipLaunchKernelGGL(ecol_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, d2_tail, lam, a, w.coarse);
@@ -1670,14 +1741,20 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, doub
             hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, -1.0, w.grad, 0.0, (const double *)nullptr, w.rcg, d.np);
             ICP_HIP_CHECK(hipMemsetAsync(w.scal, 0, sizeof(Scal), st));
             auto precondition = [&](int init) -> int {
-                if (g->dim == 3) hipLaunchKernelGGL(cg_update_prec_kernel<3>, dim3(nbv), dim3(NB), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial, nown);
-                else hipLaunchKernelGGL(cg_update_prec_kernel<2>, dim3(nbv), dim3(NB), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial, nown);
-                hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, (1u << (2 + d.NG)) - 1u, par.tot, 0);
-                if (int rc = allreduce(par, 2 + d.NG)) return rc;
-                hipLaunchKernelGGL(cg_coarse_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, x_tail, r_tail, zb_tail,
-                                   (const double *)p_tail, (const double *)Ap_tail, w.coarse, w.scal, o.cg_tol * o.cg_tol, init);
-                if (g->dim == 3) hipLaunchKernelGGL(cg_dir_prec_kernel<3>, dim3(nbt), dim3(NB), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown);
-                else hipLaunchKernelGGL(cg_dir_prec_kernel<2>, dim3(nbt), dim3(NB), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown);
+                if (g->dim == 3) hipLaunchKernelGGL(cg_update_prec_kernel<3>, dim3(nbv), dim3(g->vb), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial, nown);
+                else hipLaunchKernelGGL(cg_update_prec_kernel<2>, dim3(nbv), dim3(g->vb), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial, nown);
+                if (!par.sharded()) {
+                    hipLaunchKernelGGL(cg_sum_coarse_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, (1u << (2 + d.NG)) - 1u,
+                                       par.tot, d.NG, x_tail, r_tail, zb_tail, (const double *)p_tail, (const double *)Ap_tail, w.coarse,
+                                       w.scal, o.cg_tol * o.cg_tol, init);
+                } else {
+                    hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, (1u << (2 + d.NG)) - 1u, par.tot, 0);
+                    if (int rc = allreduce(par, 2 + d.NG)) return rc;
+                    hipLaunchKernelGGL(cg_coarse_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, x_tail, r_tail, zb_tail,
+                                       (const double *)p_tail, (const double *)Ap_tail, w.coarse, w.scal, o.cg_tol * o.cg_tol, init);
+                }
+                if (g->dim == 3) hipLaunchKernelGGL(cg_dir_prec_kernel<3>, dim3(nbt), dim3(g->vb), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown);
+                else hipLaunchKernelGGL(cg_dir_prec_kernel<2>, dim3(nbt), dim3(g->vb), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown);
                 return exchange(ctx, g, par, w.pcg);
             };
             if (int rc = precondition(1)) return rc;  // alpha = 0: z = M^-1 r, rz, rr0, p = z
@@ -1688,10 +1765,15 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, doub
                 for (int k = 0; k < chunk; ++k) {
                     if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.pcg, w.y)) return rc;
                     if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.y, w.d2, w.pcg, lam, w.Ap, false, false)) return rc;
-                    hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask | (1u << 8), par.tot, 0);
-                    if (int rc = allreduce(par, 9)) return rc;
-                    hipLaunchKernelGGL(cg_alpha_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, d2_tail,
-                                       (const double *)p_tail, lam, Ap_tail, w.scal);
+                    if (!par.sharded()) {
+                        hipLaunchKernelGGL(cg_sum_alpha_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask | (1u << 8),
+                                           par.tot, d.NG, d2_tail, (const double *)p_tail, lam, Ap_tail, w.scal);
+                    } else {
+                        hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask | (1u << 8), par.tot, 0);
+                        if (int rc = allreduce(par, 9)) return rc;
+                        hipLaunchKernelGGL(cg_alpha_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, d2_tail,
+                                           (const double *)p_tail, lam, Ap_tail, w.scal);
+                    }
                     if (int rc = precondition(0)) return rc;
                 }
                 ICP_HIP_CHECK(hipGetLastError());
