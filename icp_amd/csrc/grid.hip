@@ -296,6 +296,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     // a wave's trip count is the longest TOTAL, not the sum of per-cell maxima.
     constexpr int LIST = 8;
     __shared__ uint2 wl[LIST][QB];
+    __shared__ float wlb[LIST][QB];  // lower bound of each listed cell (rounded down)
     const int lane_slot = threadIdx.x;
 
     auto eval = [&](const double4 &rc) {
@@ -389,31 +390,56 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             if (inside && !(LE ? (bound > thr) : (bound > best))) mask |= 1u << nb;
         }
         // phase C: fetch the ranges of up to LIST surviving cells in one batch, then every lane walks
-        // its own concatenated list
+        // its own concatenated list.  Cells are taken nearest class first (faces, edges, corners) and
+        // their bound is tested again when they are drawn and again when they are walked: the best
+        // distance shrinks as cells are scanned, and the lane that holds its wave back is typically one
+        // whose own cell gave a poor first bound.
         while (__builtin_amdgcn_ballot_w64(mask != 0) != 0) {
             uint32_t r0[LIST], r1[LIST];
+            float fb[LIST];
 #pragma unroll
             for (int k = 0; k < LIST; ++k) {
-                const bool have = mask != 0;
-                const int nb = have ? __builtin_ctz(mask) : 0;
-                mask &= mask - 1;
+                bool have = mask != 0;
+                uint32_t m = mask;
+                if (DIM == 3) {
+                    constexpr uint32_t FACE = (1u << 4) | (1u << 10) | (1u << 12) | (1u << 14) | (1u << 16) | (1u << 22);
+                    constexpr uint32_t CORNER = (1u << 0) | (1u << 2) | (1u << 6) | (1u << 8) | (1u << 18) | (1u << 20) | (1u << 24) | (1u << 26);
+                    m = (mask & FACE) ? (mask & FACE) : ((mask & ~CORNER) ? (mask & ~CORNER) : mask);
+                } else {
+                    constexpr uint32_t FACE = (1u << 1) | (1u << 3) | (1u << 5) | (1u << 7);
+                    m = (mask & FACE) ? (mask & FACE) : mask;
+                }
+                const int nb = have ? __builtin_ctz(m) : 0;
+                mask &= ~(have ? (1u << nb) : 0u);
                 const int ox = nb % 3, oy = (nb / 3) % 3, oz = nb / 9;
                 uint32_t code = (ox == 0 ? sp[0][0] : (ox == 1 ? sp[0][1] : sp[0][2])) |
                                 (oy == 0 ? sp[1][0] : (oy == 1 ? sp[1][1] : sp[1][2]));
-                if (DIM == 3) code |= (oz == 0 ? sp[2][0] : (oz == 1 ? sp[2][1] : sp[2][2]));
+                double bound = (ox == 0 ? g2[0][0] : (ox == 1 ? g2[0][1] : g2[0][2])) +
+                               (oy == 0 ? g2[1][0] : (oy == 1 ? g2[1][1] : g2[1][2]));
+                if (DIM == 3) {
+                    code |= (oz == 0 ? sp[2][0] : (oz == 1 ? sp[2][1] : sp[2][2]));
+                    bound = bound + (oz == 0 ? g2[2][0] : (oz == 1 ? g2[2][1] : g2[2][2]));
+                }
+                if (!LE) have = have && !(bound > best);  // best may have improved since the mask was built
                 code = have ? code : 0u;  // exhausted mask: columns -1 may be outside the grid
                 r0[k] = start[(uint64_t)code << (DIM * l)];
                 r1[k] = have ? start[((uint64_t)code + 1) << (DIM * l)] : r0[k];
+                fb[k] = __double2float_rd(bound);  // <= bound: skipping on (double)fb > best stays exact
             }
 #pragma unroll
-            for (int k = 0; k < LIST; ++k) wl[k][lane_slot] = make_uint2(r0[k], r1[k]);
+            for (int k = 0; k < LIST; ++k) {
+                wl[k][lane_slot] = make_uint2(r0[k], r1[k]);
+                wlb[k][lane_slot] = fb[k];
+            }
             constexpr int UNR = 4;
             int cur = 0;
             uint32_t p = 0, pe = 0;
             while (true) {
                 while (p >= pe && cur < LIST) {
                     const uint2 r = wl[cur][lane_slot];
+                    const float f = wlb[cur][lane_slot];
                     ++cur;
+                    if (!LE && (double)f > best) continue;  // a tie (bound == best) is still visited
                     p = r.x;
                     pe = r.y;
                 }
