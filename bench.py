@@ -196,7 +196,8 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "closest-point queries/s over full ICP iterations (Match+FindTransform+apply+Distance), 1Mx1M pts",
+            "metric": "closest-point queries/s over full ICP iterations (Match+FindTransform+apply+Distance), %s pts" % (
+                "1Mx1M" if n == (1 << 20) else "%dx%d" % (n, n)),
             "value": n * K / dt,
             "unit": "queries/s",
             "icp_iters_per_s": K / dt,
@@ -209,8 +210,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "C2: rigid ICP, 2^20 source x 2^20 target fp64 points (N(0,1)^3, seed 1, Rz(0.3)+shift, permuted), "
-                                   "source rows sharded over %d GPU(s), target replicated" % world,
+            "config": {"workload": "%s: rigid ICP, %d source x %d target fp64 points (N(0,1)^3, seed 1, Rz(0.3)+shift, permuted), "
+                                   "source rows sharded over %d GPU(s), target replicated" % (
+                                       "C2" if n == (1 << 20) else ("C4-size" if n == (1 << 24) else "custom"), n, n, world),
                        "n_source": n, "n_target": n, "dim": 3, "search": "brute-force scan" if args.brute else "exact multi-resolution grid (bit-identical to the scan)",
                        "last_err": err_last},
             "roofline": roof,
