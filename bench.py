@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)   # C2: 30 iterations
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=1 << 20, help="source AND target points (default 2^20)")
-    ap.add_argument("--cpu-sample", type=int, default=32768)
+    ap.add_argument("--cpu-sample", type=int, default=262144, help="queries the CPU baseline matches (about 15-20 s on 16 threads)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--brute", action="store_true", help="force the brute-force closest-point kernel")
     ap.add_argument("--roofline-brute", action="store_true", help="also time one brute-force launch (adds ~1 s)")

@@ -144,3 +144,34 @@ def test_world2_outer_loop_matches_single():
     assert res[0]["c"] == res[1]["c"] == c_ref
     np.testing.assert_allclose(res[0]["errs"], [h[0] for h in hist], rtol=1e-6)
     np.testing.assert_allclose(dd, dd_ref.cpu().numpy(), rtol=1e-6, atol=1e-8)
+
+
+def test_c5_size_properties():
+    """BASELINE config C5 size on one GPU (448 x 448 = 200 704 vertices): size-independent
+    properties -- weights sum to 1, Deform(identity) is the source, <Jp, Jq> == <p, J^T J q>,
+    a bounded solve lowers the energy and is deterministic, and the single-rank sharded entry
+    point reproduces it bit for bit."""
+    import torch
+    from icp_amd import nicp, nicp_dist as nd
+    v, edges, tgt = orc.make_grid_mesh(448, 448, seed=7)
+    n = v.shape[0]
+    w = nicp.knn_weights(v)
+    np.testing.assert_allclose(w.sum(0), 1.0, atol=1e-13)
+    P0 = nicp.initial_params(n, 3)
+    np.testing.assert_allclose(nicp.deform(P0, w, v).cpu().numpy(), v, rtol=0, atol=1e-13)
+    rng = np.random.default_rng(0)
+    P = P0 + 0.01 * rng.standard_normal(P0.shape)
+    p, q = rng.standard_normal(P0.shape), rng.standard_normal(P0.shape)
+    Jp, Jq = nicp.jvp(P, w, v, edges, C, p, compat=False), nicp.jvp(P, w, v, edges, C, q, compat=False)
+    lhs = float((Jp * Jq).sum())
+    rhs = float((torch.as_tensor(p, device=Jp.device) * nicp.jtvp(P, w, v, edges, C, Jq, compat=False)).sum())
+    assert abs(lhs - rhs) <= 1e-9 * abs(lhs)
+    from icp_amd import rigid
+    nn = rigid.gather_points(w.ctx.to_dev(tgt), rigid.closest_indices(v, tgt))
+    opts = dict(max_lm_iters=2, max_cg_iters=150, cg_tol=1e-6)
+    P1, st1 = nicp.solve(P0, w, v, edges, nn, C, compat=False, opts=opts)
+    P2, st2 = nicp.solve(P0, w, v, edges, nn, C, compat=False, opts=opts)
+    assert st1["err"] < st1["err0"] and st1 == st2 and torch.equal(P1, P2)
+    sh = nd.ShardedNICP(v, w.nbr.cpu().numpy(), w.wt.cpu().numpy(), edges, tgt, world=1, rank=0)
+    st3 = sh.solve(nn, C, opts)
+    assert st3 == st1 and torch.equal(sh.P, P1)

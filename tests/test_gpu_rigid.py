@@ -239,3 +239,20 @@ def test_match_full_size_properties(api):
     rows = rng.choice(n, 2048, replace=False)
     oi, _ = c_oracle.match_idx(src[rows], tgt)
     assert np.array_equal(idx[rows], oi)
+
+
+def test_match_c4_size_properties(api):
+    """BASELINE config C4 size on one GPU (2^24 targets, one rank's 2^21-row source shard):
+    a permuted slice of the target matches itself exactly, and a sample of an independent
+    shard agrees with the C oracle."""
+    m, n = 1 << 24, 1 << 21
+    rng = np.random.default_rng(2)
+    tgt = rng.standard_normal((m, 3))
+    rows = rng.choice(m, n, replace=False)
+    idx, d2 = gpu_idx(api, tgt[rows], tgt, want_d2=True)
+    assert np.array_equal(idx, rows) and not d2.any()
+    src = tgt[rows] @ orc.rz(0.3).T + 0.01
+    idx = gpu_idx(api, src, tgt)
+    pick = rng.choice(n, 256, replace=False)
+    oi, _ = c_oracle.match_idx(src[pick], tgt)
+    assert np.array_equal(idx[pick], oi)
