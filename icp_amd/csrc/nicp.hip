@@ -66,6 +66,24 @@ struct Globals {
     double T[3];
 };
 
+// Where element (vertex j, component e) of a per-vertex array lives.  The C-ABI hands arrays in the
+// reference's layouts (P: 12 numbers per vertex in a row, points [n,dim], residual rows per vertex /
+// per edge); with one lane per vertex those are 96-byte-strided accesses that thrash the L1, so the
+// solver keeps its own copies lane-transposed (component-major: element e of vertex j at e*n + j) and
+// the same kernels serve both through these strides.  The tail (global parameters) sits at S*n in both.
+struct Strides {
+    int64_t pj, pe;  // parameter-like vectors: P, p, A p, gradient, scaling ...
+    int64_t vj, vc;  // per-vertex points: v, nn, Deform output
+    int64_t fj, fo;  // fit rows        (dim per vertex)
+    int64_t rj, rm;  // rigidity rows   (NRIG per vertex), relative to the start of the rigid block
+    int64_t sj, so;  // smoothness rows (2*dim per edge), relative to the start of the smooth block
+};
+template <int DIM>
+static inline Strides strides_aos() {
+    return {Lay<DIM>::S, 1, DIM, 1, DIM, 1, Lay<DIM>::NRIG, 1, 2 * DIM, 1};
+}
+static inline Strides strides_soa(int64_t n, int64_t ne) { return {1, n, 1, n, 1, n, 1, n, 1, ne > 0 ? ne : 1}; }
+
 // ------------------------------------------------------------------ KNN + weights
 // Exact k-nearest by the key the reference sorts on, sqrt(d2) (nicp_3d.py:53-57), with
 // ties resolved to the lower index (the C++ heap's rule, nicp3d.cpp:116-125, and what a
@@ -204,27 +222,26 @@ template <int DIM>
 __global__ __launch_bounds__(NB) void deform_kernel(const double *__restrict__ P, const int32_t *__restrict__ nbr,
                                                    const double *__restrict__ wt, int K, const double *__restrict__ v,
                                                    int64_t n, const Globals *__restrict__ g, double *__restrict__ pre_out,
-                                                   double *__restrict__ dd_out) {
+                                                   double *__restrict__ dd_out, Strides st) {
     const int64_t i = (int64_t)blockIdx.x * NB + threadIdx.x;
     if (i >= n) return;
-    constexpr int S = Lay<DIM>::S;
     double vi[DIM], pre[DIM];
 #pragma unroll
     for (int c = 0; c < DIM; ++c) {
-        vi[c] = v[i * DIM + c];
+        vi[c] = v[i * st.vj + c * st.vc];
         pre[c] = 0.0;
     }
     for (int k = 0; k < K; ++k) {
         const double w = wt[i * K + k];
         if (w == 0.0) continue;  // nicp_3d.py:227
         const int64_t j = nbr[i * K + k];
-        const double *Pj = P + j * S;
+        const double *Pj = P + j * st.pj;
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
             double a = 0.0;
 #pragma unroll
-            for (int r = 0; r < DIM; ++r) a += (vi[r] - v[j * DIM + r]) * Pj[r * DIM + c];
-            pre[c] += w * (a + v[j * DIM + c] + Pj[DIM * DIM + c]);
+            for (int r = 0; r < DIM; ++r) a += (vi[r] - v[j * st.vj + r * st.vc]) * Pj[(r * DIM + c) * st.pe];
+            pre[c] += w * (a + v[j * st.vj + c * st.vc] + Pj[(DIM * DIM + c) * st.pe]);
         }
     }
 #pragma unroll
@@ -232,8 +249,8 @@ __global__ __launch_bounds__(NB) void deform_kernel(const double *__restrict__ P
         double a = 0.0;
 #pragma unroll
         for (int c = 0; c < DIM; ++c) a += pre[c] * g->R[c * DIM + o];
-        if (dd_out) dd_out[i * DIM + o] = a + g->T[o];
-        if (pre_out) pre_out[i * DIM + o] = pre[o];
+        if (dd_out) dd_out[i * st.vj + o * st.vc] = a + g->T[o];
+        if (pre_out) pre_out[i * st.vj + o * st.vc] = pre[o];
     }
 }
 
@@ -261,42 +278,47 @@ __global__ __launch_bounds__(NB) void residual_kernel(const double *__restrict__
                                                      const double *__restrict__ nn, const double *__restrict__ dd,
                                                      const int32_t *__restrict__ edges, int64_t n, int64_t ne,
                                                      double c_fit, double c_rigid, double c_smooth,
-                                                     double *__restrict__ r) {
-    constexpr int S = Lay<DIM>::S, NRIG = Lay<DIM>::NRIG;
+                                                     double *__restrict__ r, Strides st) {
+    constexpr int NRIG = Lay<DIM>::NRIG, NA = Lay<DIM>::NA;
     const int64_t t = (int64_t)blockIdx.x * NB + threadIdx.x;
     double *r_rig = r + n * DIM, *r_sm = r + n * DIM + n * NRIG;
+    auto rig = [&](int64_t flat) { return (flat / NRIG) * st.rj + (flat % NRIG) * st.rm; };  // flat = reference slot
     if (t < n) {
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) r[t * DIM + c] = c_fit * (nn[t * DIM + c] - dd[t * DIM + c]);
-        double e[NRIG];
-        rigid_terms<DIM>(P + t * S, e);
+        for (int c = 0; c < DIM; ++c)
+            r[t * st.fj + c * st.fo] = c_fit * (nn[t * st.vj + c * st.vc] - dd[t * st.vj + c * st.vc]);
+        double A[NA], e[NRIG];
+#pragma unroll
+        for (int k = 0; k < NA; ++k) A[k] = P[t * st.pj + k * st.pe];
+        rigid_terms<DIM>(A, e);
         if (DIM == 3 && COMPAT) {
             // Q5: slot 3i..3i+5 written in ascending i: only the three orthogonality terms of
             // each vertex survive, except the last vertex which keeps all six
-            for (int m = 0; m < 3; ++m) r_rig[t * 3 + m] = c_rigid * e[m];
+            for (int m = 0; m < 3; ++m) r_rig[rig(t * 3 + m)] = c_rigid * e[m];
             if (t == n - 1)
-                for (int m = 3; m < 6; ++m) r_rig[t * 3 + m] = c_rigid * e[m];
-            for (int64_t s = 3 * n + 3 + t * 3; s < 3 * n + 3 + t * 3 + 3 && s < 6 * n; ++s) r_rig[s] = 0.0;
+                for (int m = 3; m < 6; ++m) r_rig[rig(t * 3 + m)] = c_rigid * e[m];
+            for (int64_t sl = 3 * n + 3 + t * 3; sl < 3 * n + 3 + t * 3 + 3 && sl < 6 * n; ++sl) r_rig[rig(sl)] = 0.0;
         } else {
-            for (int m = 0; m < NRIG; ++m) r_rig[t * NRIG + m] = c_rigid * e[m];
+            for (int m = 0; m < NRIG; ++m) r_rig[t * st.rj + m * st.rm] = c_rigid * e[m];
         }
     } else if (t < n + ne) {
         const int64_t ed = t - n;
         const int64_t p1 = edges[ed * 2], p2 = edges[ed * 2 + 1];
-        const double *P1 = P + p1 * S, *P2 = P + p2 * S;
+        const double *P1 = P + p1 * st.pj, *P2 = P + p2 * st.pj;
         // nicp_3d.py:261-262
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
             double a1 = 0.0, a2 = 0.0;
 #pragma unroll
             for (int rr = 0; rr < DIM; ++rr) {
-                const double d = v[p2 * DIM + rr] - v[p1 * DIM + rr];
-                a1 += d * P1[rr * DIM + c];
-                a2 += -d * P2[rr * DIM + c];
+                const double d = v[p2 * st.vj + rr * st.vc] - v[p1 * st.vj + rr * st.vc];
+                a1 += d * P1[(rr * DIM + c) * st.pe];
+                a2 += -d * P2[(rr * DIM + c) * st.pe];
             }
-            const double x1 = v[p1 * DIM + c] + P1[DIM * DIM + c], x2 = v[p2 * DIM + c] + P2[DIM * DIM + c];
-            r_sm[ed * 2 * DIM + c] = c_smooth * (a1 + x1 - x2);
-            r_sm[ed * 2 * DIM + DIM + c] = c_smooth * (a2 + x2 - x1);
+            const double x1 = v[p1 * st.vj + c * st.vc] + P1[(DIM * DIM + c) * st.pe];
+            const double x2 = v[p2 * st.vj + c * st.vc] + P2[(DIM * DIM + c) * st.pe];
+            r_sm[ed * st.sj + c * st.so] = c_smooth * (a1 + x1 - x2);
+            r_sm[ed * st.sj + (DIM + c) * st.so] = c_smooth * (a2 + x2 - x1);
         }
     }
 }
@@ -308,8 +330,8 @@ __global__ __launch_bounds__(NB) void jp_kernel(const double *__restrict__ P, co
                                                const double *__restrict__ v, const double *__restrict__ rs,
                                                const int32_t *__restrict__ edges, int64_t n, int64_t ne,
                                                const Globals *__restrict__ g, double c_fit, double c_rigid,
-                                               double c_smooth, double *__restrict__ y) {
-    constexpr int S = Lay<DIM>::S, NRIG = Lay<DIM>::NRIG, NANG = Lay<DIM>::NANG;
+                                               double c_smooth, double *__restrict__ y, Strides st) {
+    constexpr int S = Lay<DIM>::S, NRIG = Lay<DIM>::NRIG, NANG = Lay<DIM>::NANG, NA = Lay<DIM>::NA;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double *y_rig = y + n * DIM, *y_sm = y + n * DIM + n * NRIG;
     const double *ptail = p + n * S;
@@ -318,7 +340,7 @@ __global__ __launch_bounds__(NB) void jp_kernel(const double *__restrict__ P, co
         double vi[DIM], acc[DIM];
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
-            vi[c] = v[t * DIM + c];
+            vi[c] = v[t * st.vj + c * st.vc];
             acc[c] = 0.0;
         }
         for (int k0 = 0; k0 < K; k0 += 4) {  // four neighbours per batch: all gathers issued before use
@@ -333,9 +355,9 @@ __global__ __launch_bounds__(NB) void jp_kernel(const double *__restrict__ P, co
 #pragma unroll
             for (int b4 = 0; b4 < 4; ++b4) {
 #pragma unroll
-                for (int e = 0; e < S; ++e) pj[b4][e] = p[(int64_t)jj[b4] * S + e];
+                for (int e = 0; e < S; ++e) pj[b4][e] = p[(int64_t)jj[b4] * st.pj + e * st.pe];
 #pragma unroll
-                for (int r = 0; r < DIM; ++r) vn[b4][r] = v[(int64_t)jj[b4] * DIM + r];
+                for (int r = 0; r < DIM; ++r) vn[b4][r] = v[(int64_t)jj[b4] * st.vj + r * st.vc];
             }
 #pragma unroll
             for (int b4 = 0; b4 < 4; ++b4) {
@@ -359,15 +381,21 @@ __global__ __launch_bounds__(NB) void jp_kernel(const double *__restrict__ P, co
             for (int an = 0; an < NANG; ++an) {
                 double b = 0.0;
 #pragma unroll
-                for (int c = 0; c < DIM; ++c) b += rs[t * DIM + c] * g->dR[an][c * DIM + o];
+                for (int c = 0; c < DIM; ++c) b += rs[t * st.vj + c * st.vc] * g->dR[an][c * DIM + o];
                 a += ptail[an] * b;
             }
-            y[t * DIM + o] = -c_fit * a;
+            y[t * st.fj + o * st.fo] = -c_fit * a;
         }
         // rigid rows: nicp_3d.py:309-314 / nicp_row.py:193-204
-        const double *A = P + t * S, *pa = p + t * S;
+        double A[NA], pa[NA];
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            A[k] = P[t * st.pj + k * st.pe];
+            pa[k] = p[t * st.pj + k * st.pe];
+        }
         if (DIM == 3) {
             double d01 = 0, d10 = 0, d12 = 0, d21 = 0, d20 = 0, d02 = 0, d00 = 0, d11 = 0, d22 = 0;
+#pragma unroll
             for (int c = 0; c < 3; ++c) {
                 d10 += A[3 + c] * pa[c];       // a1 . pa0
                 d01 += A[c] * pa[3 + c];       // a0 . pa1
@@ -379,41 +407,42 @@ __global__ __launch_bounds__(NB) void jp_kernel(const double *__restrict__ P, co
                 d11 += A[3 + c] * pa[3 + c];
                 d22 += A[6 + c] * pa[6 + c];
             }
-            y_rig[t * 6 + 0] = c_rigid * (d10 + d01);
-            y_rig[t * 6 + 1] = c_rigid * (d21 + d12);
-            y_rig[t * 6 + 2] = c_rigid * (d20 + d02);
-            y_rig[t * 6 + 3] = c_rigid * (-2 * d00);
-            y_rig[t * 6 + 4] = c_rigid * (-2 * d11);
-            y_rig[t * 6 + 5] = c_rigid * (-2 * d22);
+            y_rig[t * st.rj + 0 * st.rm] = c_rigid * (d10 + d01);
+            y_rig[t * st.rj + 1 * st.rm] = c_rigid * (d21 + d12);
+            y_rig[t * st.rj + 2 * st.rm] = c_rigid * (d20 + d02);
+            y_rig[t * st.rj + 3 * st.rm] = c_rigid * (-2 * d00);
+            y_rig[t * st.rj + 4 * st.rm] = c_rigid * (-2 * d11);
+            y_rig[t * st.rj + 5 * st.rm] = c_rigid * (-2 * d22);
         } else {
             double d10 = 0, d01 = 0, d00 = 0, d11 = 0;
+#pragma unroll
             for (int c = 0; c < 2; ++c) {
                 d10 += A[2 + c] * pa[c];
                 d01 += A[c] * pa[2 + c];
                 d00 += A[c] * pa[c];
                 d11 += A[2 + c] * pa[2 + c];
             }
-            y_rig[t * 3 + 0] = c_rigid * (d10 + d01);
-            y_rig[t * 3 + 1] = c_rigid * (-2 * d00);
-            y_rig[t * 3 + 2] = c_rigid * (-2 * d11);
+            y_rig[t * st.rj + 0 * st.rm] = c_rigid * (d10 + d01);
+            y_rig[t * st.rj + 1 * st.rm] = c_rigid * (-2 * d00);
+            y_rig[t * st.rj + 2 * st.rm] = c_rigid * (-2 * d11);
         }
     } else if (t < n + ne) {
         // smooth rows: nicp_3d.py:316-333
         const int64_t ed = t - n;
         const int64_t p1 = edges[ed * 2], p2 = edges[ed * 2 + 1];
-        const double *q1 = p + p1 * S, *q2 = p + p2 * S;
+        const double *q1 = p + p1 * st.pj, *q2 = p + p2 * st.pj;
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
             double a1 = 0.0, a2 = 0.0;
 #pragma unroll
             for (int r = 0; r < DIM; ++r) {
-                const double d = v[p2 * DIM + r] - v[p1 * DIM + r];
-                a1 += d * q1[r * DIM + c];
-                a2 += d * q2[r * DIM + c];
+                const double d = v[p2 * st.vj + r * st.vc] - v[p1 * st.vj + r * st.vc];
+                a1 += d * q1[(r * DIM + c) * st.pe];
+                a2 += d * q2[(r * DIM + c) * st.pe];
             }
-            const double b1 = q1[DIM * DIM + c], b2 = q2[DIM * DIM + c];
-            y_sm[ed * 2 * DIM + c] = c_smooth * (a1 + b1 - b2);
-            y_sm[ed * 2 * DIM + DIM + c] = c_smooth * (-a2 + b2 - b1);
+            const double b1 = q1[(DIM * DIM + c) * st.pe], b2 = q2[(DIM * DIM + c) * st.pe];
+            y_sm[ed * st.sj + c * st.so] = c_smooth * (a1 + b1 - b2);
+            y_sm[ed * st.sj + (DIM + c) * st.so] = c_smooth * (-a2 + b2 - b1);
         }
     }
 }
@@ -431,8 +460,8 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
                                                 const Globals *__restrict__ g, double c_fit, double c_rigid,
                                                 double c_smooth, const double *__restrict__ lam_d2,
                                                 const double *__restrict__ p_in, double lam, double *__restrict__ out,
-                                                double *__restrict__ partial, int64_t nown) {
-    constexpr int S = Lay<DIM>::S, NRIG = Lay<DIM>::NRIG, NANG = Lay<DIM>::NANG, NG = Lay<DIM>::NG;
+                                                double *__restrict__ partial, int64_t nown, Strides st) {
+    constexpr int NRIG = Lay<DIM>::NRIG, NANG = Lay<DIM>::NANG, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const double *u_rig = u + n * DIM, *u_sm = u + n * DIM + n * NRIG;
     double gacc[kSumSlots];
@@ -442,7 +471,7 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
         double gA[DIM][DIM], gb[DIM], vj[DIM];
 #pragma unroll
         for (int r = 0; r < DIM; ++r) {
-            vj[r] = v[j * DIM + r];
+            vj[r] = v[j * st.vj + r * st.vc];
             gb[r] = 0.0;
 #pragma unroll
             for (int c = 0; c < DIM; ++c) gA[r][c] = 0.0;
@@ -474,8 +503,8 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
             for (int q = 0; q < RB; ++q)
 #pragma unroll
                 for (int o = 0; o < DIM; ++o) {
-                    uu[q][o] = SQUARE ? 0.0 : u[(int64_t)ii[q] * DIM + o];
-                    vv[q][o] = v[(int64_t)ii[q] * DIM + o];
+                    uu[q][o] = SQUARE ? 0.0 : u[(int64_t)ii[q] * st.fj + o * st.fo];
+                    vv[q][o] = v[(int64_t)ii[q] * st.vj + o * st.vc];
                 }
         };
         auto fit_accumulate = [&](const double (&ww)[RB], const double (&uu)[RB][DIM], const double (&vv)[RB][DIM]) {
@@ -516,9 +545,9 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
 #pragma unroll
             for (int q = 0; q < IB; ++q) {
 #pragma unroll
-                for (int o = 0; o < DIM; ++o) vo[q][o] = v[(int64_t)oth[q] * DIM + o];
+                for (int o = 0; o < DIM; ++o) vo[q][o] = v[(int64_t)oth[q] * st.vj + o * st.vc];
 #pragma unroll
-                for (int o = 0; o < 2 * DIM; ++o) us[q][o] = SQUARE ? 1.0 : u_sm[(int64_t)(ent[q] >> 1) * 2 * DIM + o];
+                for (int o = 0; o < 2 * DIM; ++o) us[q][o] = SQUARE ? 1.0 : u_sm[(int64_t)(ent[q] >> 1) * st.sj + o * st.so];
             }
         };
         auto edge_accumulate = [&](int32_t e0, const int32_t (&ent)[IB], const double (&us)[IB][2 * DIM], const double (&vo)[IB][DIM]) {
@@ -548,9 +577,9 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
         edge_entries(in_beg, ent0, oth0);
         double Aown[Lay<DIM>::NA], urown[NRIG];
 #pragma unroll
-        for (int e = 0; e < Lay<DIM>::NA; ++e) Aown[e] = P[j * S + e];
+        for (int e = 0; e < Lay<DIM>::NA; ++e) Aown[e] = P[j * st.pj + e * st.pe];
 #pragma unroll
-        for (int e = 0; e < NRIG; ++e) urown[e] = SQUARE ? 0.0 : u_rig[j * NRIG + e];
+        for (int e = 0; e < NRIG; ++e) urown[e] = SQUARE ? 0.0 : u_rig[j * st.rj + e * st.rm];
         fit_gather(ii0, uu0, vv0);
         edge_gather(ent0, oth0, us0, vo0);
 
@@ -566,7 +595,7 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
         // rigid rows of vertex j
         {
             const double *A = Aown, *ur = urown;
-            if (DIM == 3) {
+            if constexpr (DIM == 3) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const double a0 = A[c], a1 = A[3 + c], a2 = A[6 + c];
@@ -608,14 +637,14 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
         for (int r = 0; r < DIM; ++r)
 #pragma unroll
             for (int c = 0; c < DIM; ++c) {
-                const int64_t o = j * S + r * DIM + c;
+                const int64_t o = j * st.pj + (r * DIM + c) * st.pe;
                 const double val = gA[r][c] + (lam_d2 ? lam * lam_d2[o] * p_in[o] : 0.0);
                 out[o] = val;
                 if (lam_d2) pap += val * p_in[o];
             }
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
-            const int64_t o = j * S + DIM * DIM + c;
+            const int64_t o = j * st.pj + (DIM * DIM + c) * st.pe;
             const double val = gb[c] + (lam_d2 ? lam * lam_d2[o] * p_in[o] : 0.0);
             out[o] = val;
             if (lam_d2) pap += val * p_in[o];
@@ -628,13 +657,13 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
             for (int o = 0; o < DIM; ++o) {
                 double b = 0.0;
 #pragma unroll
-                for (int c = 0; c < DIM; ++c) b += rs[j * DIM + c] * g->dR[an][c * DIM + o];
-                a += SQUARE ? (c_fit * b) * (c_fit * b) : -c_fit * b * u[j * DIM + o];
+                for (int c = 0; c < DIM; ++c) b += rs[j * st.vj + c * st.vc] * g->dR[an][c * DIM + o];
+                a += SQUARE ? (c_fit * b) * (c_fit * b) : -c_fit * b * u[j * st.fj + o * st.fo];
             }
             gacc[an] = a;
         }
 #pragma unroll
-        for (int o = 0; o < DIM; ++o) gacc[NANG + o] = SQUARE ? c_fit * c_fit : -c_fit * u[j * DIM + o];
+        for (int o = 0; o < DIM; ++o) gacc[NANG + o] = SQUARE ? c_fit * c_fit : -c_fit * u[j * st.fj + o * st.fo];
     }
     // halo copies (j >= nown) belong to another rank's sums
     if (j >= nown) {
@@ -820,7 +849,7 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
                                                        int64_t n, const Globals *__restrict__ g, double c_fit, double c_rigid,
                                                        double c_smooth, const double *__restrict__ col2,
                                                        const double *__restrict__ d2, double lam,
-                                                       double *__restrict__ binv, Coarse *__restrict__ coarse) {
+                                                       double *__restrict__ binv, Coarse *__restrict__ coarse, Strides st) {
     constexpr int S = Lay<DIM>::S, NA = Lay<DIM>::NA, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (j == 0)
@@ -837,7 +866,7 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
             M[a][b] = m;
         }
     double vj[DIM];
-    for (int a = 0; a < DIM; ++a) vj[a] = v[j * DIM + a];
+    for (int a = 0; a < DIM; ++a) vj[a] = v[j * st.vj + a * st.vc];
     // fit rows that reference vertex j: entries -c_fit w d[r] R[c][o] (A) and -c_fit wb R[c][o] (b)
     for (int32_t e = rev_ptr[j]; e < rev_ptr[j + 1]; ++e) {
         const int32_t ent = rev_ent[e];
@@ -847,7 +876,7 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
         const double wb = (DIM == 2 && COMPAT) ? 1.0 : w;
         double u[S];  // the row pattern up to the R factor: u[r*DIM+c] = w d[r], u[NA+c] = wb (for column c)
         double d[DIM];
-        for (int a = 0; a < DIM; ++a) d[a] = v[i * DIM + a] - vj[a];
+        for (int a = 0; a < DIM; ++a) d[a] = v[i * st.vj + a * st.vc] - vj[a];
         const double cf2 = c_fit * c_fit;
         for (int r = 0; r < DIM; ++r)
             for (int c = 0; c < DIM; ++c) {
@@ -865,7 +894,8 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
     }
     // rigid rows: gradients of the NRIG terms w.r.t. the NA entries of A_j
     {
-        const double *A = P + j * S;
+        double A[NA];
+        for (int e = 0; e < NA; ++e) A[e] = P[j * st.pj + e * st.pe];
         const double cr2 = c_rigid * c_rigid;
         constexpr int NRIG = Lay<DIM>::NRIG;
         double G[NRIG][NA];
@@ -898,7 +928,7 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
         const int64_t p1 = edges[ed * 2], p2 = edges[ed * 2 + 1];
         const double cs2 = c_smooth * c_smooth;
         double d[DIM];
-        for (int a = 0; a < DIM; ++a) d[a] = v[p2 * DIM + a] - v[p1 * DIM + a];
+        for (int a = 0; a < DIM; ++a) d[a] = v[p2 * st.vj + a * st.vc] - v[p1 * st.vj + a * st.vc];
         for (int c = 0; c < DIM; ++c) {
             for (int r = 0; r < DIM; ++r) {
                 for (int r2 = 0; r2 < DIM; ++r2) B[r * DIM + c][r2 * DIM + c] += cs2 * d[r] * d[r2];
@@ -908,7 +938,7 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
             B[NA + c][NA + c] += 2 * cs2;
         }
     }
-    for (int a = 0; a < S; ++a) B[a][a] += lam * d2[j * S + a];
+    for (int a = 0; a < S; ++a) B[a][a] += lam * d2[j * st.pj + a * st.pe];
     // Cholesky B = L L^T, Linv, Binv = Linv^T Linv; on breakdown fall back to the diagonal
     double L[S][S];
     bool ok = true;
@@ -954,16 +984,19 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
 // column a of Z as a full parameter vector
 template <int DIM>
 __global__ __launch_bounds__(NB) void zcol_kernel(const double *__restrict__ P, const double *__restrict__ v, int64_t n,
-                                                 int a, double *__restrict__ out) {
+                                                 int a, double *__restrict__ out, Strides st) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) {
         double z[NG][S];
-        zmodes<DIM>(P + j * S, v + j * DIM, z);
+        double Pj_[S], vj_[DIM];
+        for (int e = 0; e < S; ++e) Pj_[e] = P[j * st.pj + e * st.pe];
+        for (int c = 0; c < DIM; ++c) vj_[c] = v[j * st.vj + c * st.vc];
+        zmodes<DIM>(Pj_, vj_, z);
         for (int e = 0; e < S; ++e) {
             double val = 0.0;
             for (int k = 0; k < NG; ++k) val = (k == a) ? z[k][e] : val;
-            out[j * S + e] = val;
+            out[j * st.pj + e * st.pe] = val;
         }
     } else if (j < n + NG) {
         out[n * S + (j - n)] = (a - NG == (int)(j - n)) ? 1.0 : 0.0;
@@ -973,16 +1006,19 @@ __global__ __launch_bounds__(NB) void zcol_kernel(const double *__restrict__ P, 
 // partial[b][k] = sum over the block's vertices of z_k(j) . r_j  (k < NG)
 template <int DIM>
 __global__ __launch_bounds__(NB) void zt_kernel(const double *__restrict__ P, const double *__restrict__ v, int64_t n,
-                                               const double *__restrict__ r, double *__restrict__ partial) {  // n = owned vertices
+                                               const double *__restrict__ r, double *__restrict__ partial, Strides st) {  // n = owned vertices
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc[NG];
     for (int k = 0; k < NG; ++k) acc[k] = 0.0;
     if (j < n) {
         double z[NG][S];
-        zmodes<DIM>(P + j * S, v + j * DIM, z);
+        double Pj_[S], vj_[DIM];
+        for (int e = 0; e < S; ++e) Pj_[e] = P[j * st.pj + e * st.pe];
+        for (int c = 0; c < DIM; ++c) vj_[c] = v[j * st.vj + c * st.vc];
+        zmodes<DIM>(Pj_, vj_, z);
         for (int k = 0; k < NG; ++k)
-            for (int e = 0; e < S; ++e) acc[k] += z[k][e] * r[j * S + e];
+            for (int e = 0; e < S; ++e) acc[k] += z[k][e] * r[j * st.pj + e * st.pe];
     }
     __shared__ double red[NB / 64][NG];
     const int tid = threadIdx.x;
@@ -1137,11 +1173,39 @@ __global__ void add_tail_dot_kernel(double *__restrict__ tot, int slot, const do
     tot[slot] += s;
 }
 
-// halo packing: buf[i*S + e] = vec[idx[i]*S + e]
+// halo packing: buf[i*S + e] = vec(idx[i], e); unpacking: vec(first + h, e) = buf[h*S + e]
 __global__ __launch_bounds__(NB) void pack_kernel(const double *__restrict__ vec, const int32_t *__restrict__ idx, int64_t cnt,
-                                                 int S, double *__restrict__ buf) {
+                                                 int S, double *__restrict__ buf, Strides st) {
     const int64_t t = (int64_t)blockIdx.x * NB + threadIdx.x;
-    if (t < cnt * S) buf[t] = vec[(int64_t)idx[t / S] * S + t % S];
+    if (t < cnt * S) buf[t] = vec[(int64_t)idx[t / S] * st.pj + (t % S) * st.pe];
+}
+__global__ __launch_bounds__(NB) void unpack_kernel(double *__restrict__ vec, int64_t first, int64_t cnt, int S,
+                                                   const double *__restrict__ buf, Strides st) {
+    const int64_t t = (int64_t)blockIdx.x * NB + threadIdx.x;
+    if (t < cnt * S) vec[(first + t / S) * st.pj + (t % S) * st.pe] = buf[t];
+}
+
+// dst(j, e) = src(j, e) for a [cnt, width] array between two layouts (row strides sj, element strides se)
+__global__ __launch_bounds__(NB) void relayout_kernel(const double *__restrict__ src, int64_t sj, int64_t se,
+                                                     double *__restrict__ dst, int64_t dj, int64_t de, int64_t cnt, int width) {
+    const int64_t t = (int64_t)blockIdx.x * NB + threadIdx.x;
+    if (t < cnt * width) {
+        const int64_t j = t % cnt;
+        const int e = (int)(t / cnt);
+        dst[j * dj + e * de] = src[j * sj + e * se];
+    }
+}
+
+// partial[b] = sum of a*b*(w?w:1) over the OWNED part of a parameter vector: vertices [0, nown), all S components
+__global__ __launch_bounds__(NB) void dot_owned_kernel(const double *__restrict__ a, const double *__restrict__ b,
+                                                      const double *__restrict__ w, int64_t nown, int S, Strides st,
+                                                      double *__restrict__ partial) {
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * NB + threadIdx.x; i < nown * S; i += (int64_t)gridDim.x * NB) {
+        const int64_t o = (i % nown) * st.pj + (i / nown) * st.pe;
+        s += a[o] * b[o] * (w ? w[o] : 1.0);
+    }
+    block_sum_to(s, partial);
 }
 
 // x += alpha p; r -= alpha Ap; zb = Binv r (per vertex); partials: r.zb, r.r, Z^T r.
@@ -1152,35 +1216,58 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(const Scal *__restri
                                                            double *__restrict__ x, double *__restrict__ r,
                                                            double *__restrict__ zb, const double *__restrict__ p,
                                                            const double *__restrict__ Ap, const double *__restrict__ binv,
-                                                           double *__restrict__ partial, int64_t nown) {
+                                                           double *__restrict__ partial, int64_t nown, Strides st) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc[2 + NG];
     for (int k = 0; k < 2 + NG; ++k) acc[k] = 0.0;
     if (j < nown && !s->stop) {
         const double alpha = s->alpha;
-        double rj[S], zj[S];
+        // every load first, every store last: with run-time strides the compiler cannot tell x[o_e] from
+        // x[o_e'] and would otherwise wait for each store before the next load (12 round trips in a row)
+        double xj[S], rj[S], pj[S], apj[S], zj[S], Pj_[S], vj_[DIM];
+#pragma unroll
         for (int e = 0; e < S; ++e) {
-            x[j * S + e] += alpha * p[j * S + e];
-            rj[e] = r[j * S + e] - alpha * Ap[j * S + e];
-            r[j * S + e] = rj[e];
+            const int64_t o = j * st.pj + e * st.pe;
+            xj[e] = x[o];
+            rj[e] = r[o];
+            pj[e] = p[o];
+            apj[e] = Ap[o];
+            Pj_[e] = P[o];
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) vj_[c] = v[j * st.vj + c * st.vc];
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            xj[e] += alpha * pj[e];
+            rj[e] = rj[e] - alpha * apj[e];
             zj[e] = 0.0;
         }
         const double *B = binv + j;
         int q = 0;
+#pragma unroll
         for (int a = 0; a < S; ++a)
+#pragma unroll
             for (int b = 0; b <= a; ++b) {
                 const double m = B[(int64_t)(q++) * n];
                 zj[a] += m * rj[b];
                 if (a != b) zj[b] += m * rj[a];
             }
         double z[NG][S];
-        zmodes<DIM>(P + j * S, v + j * DIM, z);
+        zmodes<DIM>(Pj_, vj_, z);
+#pragma unroll
         for (int e = 0; e < S; ++e) {
-            zb[j * S + e] = zj[e];
             acc[0] += rj[e] * zj[e];
             acc[1] += rj[e] * rj[e];
+#pragma unroll
             for (int k = 0; k < NG; ++k) acc[2 + k] += z[k][e] * rj[e];
+        }
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            const int64_t o = j * st.pj + e * st.pe;
+            x[o] = xj[e];
+            r[o] = rj[e];
+            zb[o] = zj[e];
         }
     }
     __shared__ double red[NB / 64][2 + NG];
@@ -1201,20 +1288,36 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(const Scal *__restri
 template <int DIM>
 __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(const Scal *__restrict__ s, const Coarse *__restrict__ coarse,
                                                         const double *__restrict__ P, const double *__restrict__ v, int64_t n,
-                                                        const double *__restrict__ zb, double *__restrict__ p, int64_t nown) {
+                                                        const double *__restrict__ zb, double *__restrict__ p, int64_t nown,
+                                                        Strides st) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
     if (s->stop) return;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const double beta = s->beta;
     if (j < n) {
         if (j >= nown) return;  // halo copy
-        double z[NG][S];
-        zmodes<DIM>(P + j * S, v + j * DIM, z);
-        for (int e = 0; e < S; ++e) {
-            double val = zb[j * S + e];
-            for (int k = 0; k < NG; ++k) val += coarse->y[k] * z[k][e];
-            p[j * S + e] = val + beta * p[j * S + e];
+        double z[NG][S], Pj_[S], vj_[DIM], zbj[S], pj[S], yk[NG];
+#pragma unroll
+        for (int e = 0; e < S; ++e) {  // loads first, stores last (see cg_update_prec_kernel)
+            const int64_t o = j * st.pj + e * st.pe;
+            Pj_[e] = P[o];
+            zbj[e] = zb[o];
+            pj[e] = p[o];
         }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) vj_[c] = v[j * st.vj + c * st.vc];
+#pragma unroll
+        for (int k = 0; k < NG; ++k) yk[k] = coarse->y[k];
+        zmodes<DIM>(Pj_, vj_, z);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            double val = zbj[e];
+#pragma unroll
+            for (int k = 0; k < NG; ++k) val += yk[k] * z[k][e];
+            pj[e] = val + beta * pj[e];
+        }
+#pragma unroll
+        for (int e = 0; e < S; ++e) p[j * st.pj + e * st.pe] = pj[e];
     } else if (j < n + NG) {
         const int k = (int)(j - n);
         p[n * S + k] = zb[n * S + k] + coarse->y[NG + k] + beta * p[n * S + k];
@@ -1257,13 +1360,15 @@ struct Work {
     double *binv;                          // n * S(S+1)/2: inverted diagonal blocks
     Coarse *coarse;
     double *tot;                           // 64 reduced sums (the all-reduce buffer when no comm is given)
+    double *xs, *vs, *nns, *masks;         // solver-internal (lane-transposed) copies of P, v, nn and the row mask
+    Strides st;                            // layout the helpers below index with (reference layout by default)
 };
 
 static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     const Dims d = dims_of(g);
     const size_t small = 1024;  // Globals + Scal + Coarse, in doubles (generous)
     const size_t tri = (size_t)d.S * (d.S + 1) / 2;
-    const size_t need = small + (size_t)kMaxPartials * kSumSlots + 2 * (size_t)d.n * d.dim + 3 * (size_t)d.nr + 10 * (size_t)d.np +
+    const size_t need = small + (size_t)kMaxPartials * kSumSlots + 4 * (size_t)d.n * d.dim + 4 * (size_t)d.nr + 11 * (size_t)d.np +
                         (size_t)d.n * tri + 64;
     if (g->ws_doubles < need) {
         if (g->ws) {
@@ -1295,7 +1400,12 @@ static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
         *b = p;
         p += d.np;
     }
-    w.binv = p;
+    w.binv = p; p += (size_t)d.n * tri;
+    w.xs = p; p += d.np;
+    w.vs = p; p += (size_t)d.n * d.dim;
+    w.nns = p; p += (size_t)d.n * d.dim;
+    w.masks = p;
+    w.st = d.dim == 3 ? strides_aos<3>() : strides_aos<2>();
     return ICP_OK;
 }
 
@@ -1315,10 +1425,10 @@ static int linearise(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, cons
     hipStream_t st = ctx->stream;
     if (g->dim == 3) {
         hipLaunchKernelGGL(globals_kernel<3>, dim3(1), dim3(1), 0, st, P, g->n, w.glob);
-        hipLaunchKernelGGL(deform_kernel<3>, dim3(grid_for(g->n, 1 << 30)), dim3(NB), 0, st, P, g->nbr, g->wt, g->k, v, g->n, w.glob, w.pre, w.dd);
+        hipLaunchKernelGGL(deform_kernel<3>, dim3(grid_for(g->n, 1 << 30)), dim3(NB), 0, st, P, g->nbr, g->wt, g->k, v, g->n, w.glob, w.pre, w.dd, w.st);
     } else {
         hipLaunchKernelGGL(globals_kernel<2>, dim3(1), dim3(1), 0, st, P, g->n, w.glob);
-        hipLaunchKernelGGL(deform_kernel<2>, dim3(grid_for(g->n, 1 << 30)), dim3(NB), 0, st, P, g->nbr, g->wt, g->k, v, g->n, w.glob, w.pre, w.dd);
+        hipLaunchKernelGGL(deform_kernel<2>, dim3(grid_for(g->n, 1 << 30)), dim3(NB), 0, st, P, g->nbr, g->wt, g->k, v, g->n, w.glob, w.pre, w.dd, w.st);
     }
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
@@ -1330,7 +1440,7 @@ static int residual_at(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, co
     const int nbk = grid_for(g->n + g->e, 1 << 30);
     NICP_DISPATCH(g->dim, compat,
                   hipLaunchKernelGGL((residual_kernel<D, C>), dim3(nbk), dim3(NB), 0, ctx->stream, P, v, nn, w.dd, g->edges,
-                                     g->n, g->e, c[0], c[1], c[2], r_out));
+                                     g->n, g->e, c[0], c[1], c[2], r_out, w.st));
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
 }
@@ -1342,7 +1452,7 @@ static int apply_J(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, const 
     const double *rs = compat ? w.dd : w.pre;  // Q6
     NICP_DISPATCH(g->dim, compat,
                   hipLaunchKernelGGL((jp_kernel<D, C>), dim3(nbk), dim3(g->vb), 0, ctx->stream, P, p, g->nbr, g->wt, g->k, v, rs,
-                                     g->edges, g->n, g->e, w.glob, c[0], c[1], c[2], y));
+                                     g->edges, g->n, g->e, w.glob, c[0], c[1], c[2], y, w.st));
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
 }
@@ -1376,13 +1486,13 @@ static int allreduce(const Par &par, int count) {
 }
 
 // refresh the halo copies [nown, n) of a per-vertex vector from their owners
-static int exchange(icp_ctx *ctx, const nicp_graph *g, const Par &par, double *vec) {
+static int exchange(icp_ctx *ctx, const nicp_graph *g, const Work &w, const Par &par, double *vec) {
     if (!par.sharded()) return ICP_OK;
     const nicp_comm *cm = par.comm;
     const int S = g->dim * g->dim + g->dim;
     if (cm->n_send > 0)
         hipLaunchKernelGGL(pack_kernel, dim3(grid_for(cm->n_send * S, 1 << 30)), dim3(NB), 0, ctx->stream, (const double *)vec,
-                           cm->send_idx_dev, cm->n_send, S, cm->send_buf_dev);
+                           cm->send_idx_dev, cm->n_send, S, cm->send_buf_dev, w.st);
     ICP_HIP_CHECK(hipGetLastError());
     if (int rc = cm->exchange(cm->user)) {
         set_error("nicp_solve_dist: the halo-exchange callback failed (%d)", rc);
@@ -1390,8 +1500,9 @@ static int exchange(icp_ctx *ctx, const nicp_graph *g, const Par &par, double *v
     }
     const int64_t nh = g->n - par.nown;
     if (nh > 0)
-        ICP_HIP_CHECK(hipMemcpyAsync(vec + par.nown * S, cm->recv_buf_dev, (size_t)nh * S * sizeof(double), hipMemcpyDeviceToDevice,
-                                     ctx->stream));
+        hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(nh * S, 1 << 30)), dim3(NB), 0, ctx->stream, vec, par.nown, nh, S,
+                           (const double *)cm->recv_buf_dev, w.st);
+    ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
 }
 
@@ -1412,12 +1523,12 @@ static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const 
         NICP_DISPATCH(g->dim, compat,
                       hipLaunchKernelGGL((jtu_kernel<D, C, true>), dim3(nbk), dim3(g->vb), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,
                                          rs, g->edges, g->rev_ptr, g->rev_i, g->rev_w, g->inc_ptr, g->inc_ent, g->inc_other, g->n, g->e, w.glob,
-                                         c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial, par.nown));
+                                         c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial, par.nown, w.st));
     } else {
         NICP_DISPATCH(g->dim, compat,
                       hipLaunchKernelGGL((jtu_kernel<D, C, false>), dim3(nbk), dim3(g->vb), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,
                                          rs, g->edges, g->rev_ptr, g->rev_i, g->rev_w, g->inc_ptr, g->inc_ent, g->inc_other, g->n, g->e, w.glob,
-                                         c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial, par.nown));
+                                         c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial, par.nown, w.st));
     }
     ICP_HIP_CHECK(hipGetLastError());
     if (!finish_tail) return ICP_OK;
@@ -1440,7 +1551,9 @@ static int dot_slot(icp_ctx *ctx, Work &w, const Par &par, const double *a, cons
 // parameter-vector dot: owned vertices + (on rank 0) the replicated tail
 static int pdot_slot(icp_ctx *ctx, const nicp_graph *g, Work &w, const Par &par, const double *a, const double *b, const double *wv, int slot) {
     const Dims d = dims_of(g);
-    if (int rc = dot_slot(ctx, w, par, a, b, wv, par.nown * d.S, slot)) return rc;
+    const int nbk = grid_for(par.nown * d.S);
+    hipLaunchKernelGGL(dot_owned_kernel, dim3(nbk), dim3(NB), 0, ctx->stream, a, b, wv, par.nown, d.S, w.st, w.partial);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NB), 0, ctx->stream, (const double *)w.partial, nbk, par.tot + slot);
     if (par.rank() == 0)
         hipLaunchKernelGGL(add_tail_dot_kernel, dim3(1), dim3(64), 0, ctx->stream, par.tot, slot, a + d.n * d.S, b + d.n * d.S,
                            wv ? wv + d.n * d.S : nullptr, d.NG);
@@ -1657,8 +1770,18 @@ extern "C" int nicp_jtvp(icp_ctx *ctx, nicp_graph *g, const double *P, const dou
 // Levenberg-Marquardt with two-level preconditioned CG; par says whether this is the whole mesh
 // or one rank's shard.  Every host decision below is taken from all-reduced sums, so the ranks
 // of a sharded solve follow the same control flow without further agreement.
-static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, double *P_inout, const double *v, const double *nn,
-                      const double *c3_host, unsigned flags, const nicp_solve_opts *opts_in, nicp_solve_stats *stats_out) {
+static int relayout(icp_ctx *ctx, const double *src, int64_t sj, int64_t se, double *dst, int64_t dj, int64_t de, int64_t cnt,
+                    int width) {
+    if (cnt <= 0) return ICP_OK;
+    hipLaunchKernelGGL(relayout_kernel, dim3(grid_for(cnt * width, 1 << 30)), dim3(NB), 0, ctx->stream, src, sj, se, dst, dj, de, cnt,
+                       width);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, double *P_inout, const double *v_ext,
+                      const double *nn_ext, const double *c3_host, unsigned flags, const nicp_solve_opts *opts_in,
+                      nicp_solve_stats *stats_out) {
     const bool compat = flags & 1u;
     const Dims d = dims_of(g);
     nicp_solve_opts o = {1.49012e-8, 1.49012e-8, 0.0, 1e-3, 1e-10, 100, 0};
@@ -1670,9 +1793,25 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, doub
     double ht[8];
     nicp_solve_stats stt = {0, 0, 0, 0, 0, 0};
     const int nbp = grid_for(d.np);
-    const int64_t nown = par.nown;
+    const int64_t nown = par_in.nown;
 
-    double *x = P_inout;
+    // ---- solver-internal, lane-transposed copies of the inputs (see Strides)
+    const Strides ext = w.st, soa = strides_soa(d.n, d.e);
+    Par par = par_in;
+    if (int rc = relayout(ctx, P_inout, ext.pj, ext.pe, w.xs, soa.pj, soa.pe, d.n, d.S)) return rc;
+    ICP_HIP_CHECK(hipMemcpyAsync(w.xs + d.n * d.S, P_inout + d.n * d.S, d.NG * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (int rc = relayout(ctx, v_ext, ext.vj, ext.vc, w.vs, soa.vj, soa.vc, d.n, d.dim)) return rc;
+    if (int rc = relayout(ctx, nn_ext, ext.vj, ext.vc, w.nns, soa.vj, soa.vc, d.n, d.dim)) return rc;
+    if (par.row_mask) {
+        const int64_t o_rig = d.n * d.dim, o_sm = d.n * d.dim + d.n * d.NRIG;
+        if (int rc = relayout(ctx, par.row_mask, ext.fj, ext.fo, w.masks, soa.fj, soa.fo, d.n, d.dim)) return rc;
+        if (int rc = relayout(ctx, par.row_mask + o_rig, ext.rj, ext.rm, w.masks + o_rig, soa.rj, soa.rm, d.n, d.NRIG)) return rc;
+        if (int rc = relayout(ctx, par.row_mask + o_sm, ext.sj, ext.so, w.masks + o_sm, soa.sj, soa.so, d.e, 2 * d.dim)) return rc;
+        par.row_mask = w.masks;
+    }
+    w.st = soa;
+    double *x = w.xs;
+    const double *v = w.vs, *nn = w.nns;
     if (int rc = residual_at(ctx, g, w, x, v, nn, c, compat, w.r)) return rc;
     if (int rc = dot_slot(ctx, w, par, w.r, w.r, par.row_mask, d.nr, 0)) return rc;
     if (int rc = allreduce(par, 1)) return rc;
@@ -1712,16 +1851,16 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, doub
                                              (const double *)g->wt, g->k, v, (const int32_t *)g->edges, (const int32_t *)g->rev_ptr,
                                              (const int32_t *)g->rev_ent, (const int32_t *)g->inc_ptr, (const int32_t *)g->inc_ent, d.n,
                                              (const Globals *)w.glob, c[0], c[1], c[2], (const double *)w.col2, (const double *)w.d2, lam,
-                                             w.binv, w.coarse));
+                                             w.binv, w.coarse, w.st));
             ICP_HIP_CHECK(hipGetLastError());
             for (int a = 0; a < nz; ++a) {  // E[:, a] = Z^T (J^T J + lam D^2) z_a
-                if (g->dim == 3) hipLaunchKernelGGL(zcol_kernel<3>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z);
-                else hipLaunchKernelGGL(zcol_kernel<2>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z);
+                if (g->dim == 3) hipLaunchKernelGGL(zcol_kernel<3>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z, w.st);
+                else hipLaunchKernelGGL(zcol_kernel<2>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z, w.st);
                 if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.z, w.y)) return rc;
                 if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.y, w.d2, w.z, lam, w.Ap, false, false)) return rc;
                 hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask, par.tot, 8);
-                if (g->dim == 3) hipLaunchKernelGGL(zt_kernel<3>, dim3(nbv), dim3(g->vb), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial);
-                else hipLaunchKernelGGL(zt_kernel<2>, dim3(nbv), dim3(g->vb), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial);
+                if (g->dim == 3) hipLaunchKernelGGL(zt_kernel<3>, dim3(nbv), dim3(g->vb), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial, w.st);
+                else hipLaunchKernelGGL(zt_kernel<2>, dim3(nbv), dim3(g->vb), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial, w.st);
                 hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, ng_mask, par.tot, 0);
                 if (int rc = allreduce(par, 16)) return rc;
                 hipLaunchKernelGGL(ecol_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, d2_tail, lam, a, w.coarse);
@@ -1741,8 +1880,8 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, doub
             hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, -1.0, w.grad, 0.0, (const double *)nullptr, w.rcg, d.np);
             ICP_HIP_CHECK(hipMemsetAsync(w.scal, 0, sizeof(Scal), st));
             auto precondition = [&](int init) -> int {
-                if (g->dim == 3) hipLaunchKernelGGL(cg_update_prec_kernel<3>, dim3(nbv), dim3(g->vb), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial, nown);
-                else hipLaunchKernelGGL(cg_update_prec_kernel<2>, dim3(nbv), dim3(g->vb), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial, nown);
+                if (g->dim == 3) hipLaunchKernelGGL(cg_update_prec_kernel<3>, dim3(nbv), dim3(g->vb), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial, nown, w.st);
+                else hipLaunchKernelGGL(cg_update_prec_kernel<2>, dim3(nbv), dim3(g->vb), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial, nown, w.st);
                 if (!par.sharded()) {
                     hipLaunchKernelGGL(cg_sum_coarse_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, (1u << (2 + d.NG)) - 1u,
                                        par.tot, d.NG, x_tail, r_tail, zb_tail, (const double *)p_tail, (const double *)Ap_tail, w.coarse,
@@ -1753,9 +1892,9 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, doub
                     hipLaunchKernelGGL(cg_coarse_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, x_tail, r_tail, zb_tail,
                                        (const double *)p_tail, (const double *)Ap_tail, w.coarse, w.scal, o.cg_tol * o.cg_tol, init);
                 }
-                if (g->dim == 3) hipLaunchKernelGGL(cg_dir_prec_kernel<3>, dim3(nbt), dim3(g->vb), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown);
-                else hipLaunchKernelGGL(cg_dir_prec_kernel<2>, dim3(nbt), dim3(g->vb), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown);
-                return exchange(ctx, g, par, w.pcg);
+                if (g->dim == 3) hipLaunchKernelGGL(cg_dir_prec_kernel<3>, dim3(nbt), dim3(g->vb), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown, w.st);
+                else hipLaunchKernelGGL(cg_dir_prec_kernel<2>, dim3(nbt), dim3(g->vb), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown, w.st);
+                return exchange(ctx, g, w, par, w.pcg);
             };
             if (int rc = precondition(1)) return rc;  // alpha = 0: z = M^-1 r, rz, rr0, p = z
             ICP_HIP_CHECK(hipGetLastError());
@@ -1782,7 +1921,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, doub
                 cg_done = hs.stop;
             }
             stt.cg_iters += hs.iters;
-            if (int rc = exchange(ctx, g, par, w.delta)) return rc;
+            if (int rc = exchange(ctx, g, w, par, w.delta)) return rc;
             // ---- trial point and gain ratio
             hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, 1.0, (const double *)x, 1.0, (const double *)w.delta, w.x_trial, d.np);
             // predicted reduction of |r|^2 : delta^T (lam D^2 delta - grad)
@@ -1826,6 +1965,10 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, doub
     stt.info = info;
     stt.err = f2;
     if (stats_out) *stats_out = stt;
+    // back to the caller's layout
+    w.st = ext;
+    if (int rc = relayout(ctx, x, soa.pj, soa.pe, P_inout, ext.pj, ext.pe, d.n, d.S)) return rc;
+    ICP_HIP_CHECK(hipMemcpyAsync(P_inout + d.n * d.S, x + d.n * d.S, d.NG * sizeof(double), hipMemcpyDeviceToDevice, st));
     ICP_HIP_CHECK(hipStreamSynchronize(st));
     return ICP_OK;
 }
