@@ -88,3 +88,44 @@ def test_obj_agrees_with_cxx_loader_rule(tmp_path):
     want = {tuple(sorted(map(int, r))) for r in edges}
     got = {tuple(map(int, r)) for r in e2}
     assert got == want and len(e2) == len(edges)
+
+
+def test_ply_ascii_and_binary(tmp_path):
+    v, edges, tgt = orc.make_grid_mesh(4, 3, seed=2)
+    # ascii PLY with float vertices + faces (uchar count, int indices) and an extra vertex property
+    idx = np.arange(12).reshape(4, 3)
+    faces = []
+    for i in range(3):
+        for j in range(2):
+            faces += [(idx[i, j], idx[i + 1, j], idx[i + 1, j + 1]), (idx[i, j], idx[i + 1, j + 1], idx[i, j + 1])]
+    txt = ["ply", "format ascii 1.0", "comment made by a test", "element vertex 12", "property double x", "property double y",
+           "property double z", "property uchar red", "element face %d" % len(faces), "property list uchar int vertex_indices",
+           "end_header"]
+    txt += ["%.17g %.17g %.17g 255" % tuple(p) for p in v]
+    txt += ["3 %d %d %d" % f for f in faces]
+    pa = tmp_path / "a.ply"
+    pa.write_text("\n".join(txt) + "\n")
+    va, ea = meshio.load_ply(str(pa))
+    np.testing.assert_array_equal(va, v)
+    assert {tuple(r) for r in ea.tolist()} == {tuple(sorted(map(int, r))) for r in edges} and len(ea) == len(edges)
+    # binary round trip through the reference's names
+    pb = tmp_path / "b.ply"
+    meshio.save_ply(str(pb), v, edges)
+    vb, eb = meshio.GetVerticesEdges(str(pb))
+    np.testing.assert_array_equal(vb, v)
+    assert {tuple(sorted(map(int, r))) for r in eb} == {tuple(sorted(map(int, r))) for r in edges}
+    meshio.ModifyVertices(str(pb), tgt, out=str(tmp_path / "c.ply"))
+    vc, ec = meshio.GetVerticesEdges(str(tmp_path / "c.ply"))
+    np.testing.assert_array_equal(vc, tgt)
+    np.testing.assert_array_equal(ec, eb)
+    # big-endian binary with float32 vertices
+    pe = tmp_path / "e.ply"
+    with open(pe, "wb") as f:
+        f.write(b"ply\nformat binary_big_endian 1.0\nelement vertex 2\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
+        f.write(np.array([[1, 2, 3], [4, 5, 6]], ">f4").tobytes())
+    ve, ee = meshio.load_ply(str(pe))
+    np.testing.assert_array_equal(ve, [[1, 2, 3], [4, 5, 6]])
+    assert ee.shape == (0, 2)
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.ply").write_text("plx\n")
+        meshio.load_ply(str(tmp_path / "bad.ply"))
