@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libicp_hip.so")
 ICP_COMPARE_SQRT = 1
 ICP_FORCE_BRUTE = 2
 ICP_FORCE_GRID = 4
+ICP_HINT_IDX = 8
 
 c_dp = ctypes.c_void_p
 c_i64 = ctypes.c_int64

@@ -352,7 +352,8 @@ int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *t
     }
     const bool use_grid = grid && grid->usable && !(flags & ICP_FORCE_BRUTE);
     auto argmin = [&](double *d2) -> int {
-        if (use_grid) return grid_query(ctx, *grid, src, n, nullptr, false, nullptr, idx_out, d2, done);
+        if (use_grid) return grid_query(ctx, *grid, src, n, nullptr, false, nullptr, idx_out, d2, done,
+                                        (flags & ICP_HINT_IDX) ? idx_out : nullptr);
         return dim == 3 ? launch_closest<3, false>(ctx, src, n, tgt, m, nullptr, idx_out, d2, done)
                         : launch_closest<2, false>(ctx, src, n, tgt, m, nullptr, idx_out, d2, done);
     };

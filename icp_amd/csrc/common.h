@@ -73,6 +73,8 @@ struct GridBuild {
     int32_t *sidx = nullptr;    // their original indices
     void *recs = nullptr;       // the same as 32-byte records {x, y, z, index} (double4)
     uint32_t *start = nullptr;  // [ncell+1] first sorted position of every finest cell
+    uint32_t *inv = nullptr;    // [m] sorted position of every original index (for ICP_HINT_IDX)
+    int64_t m = 0;
     bool usable = false;        // false: non-finite targets -> use the brute-force scan
 };
 // slot 0: target grid (grid_* scratch); slot 1: query ordering (sort_* scratch)
@@ -81,7 +83,7 @@ int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &g
 int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, Scratch &sa, Scratch &sb,
                     Scratch &sc, Scratch &sd);
 int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
-               const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done);
+               const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done, const int32_t *hint = nullptr);
 int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
                      unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done,
                      const GridBuild *grid = nullptr);

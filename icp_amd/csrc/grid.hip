@@ -210,7 +210,7 @@ __global__ __launch_bounds__(GB) void scan_add_kernel(uint32_t *__restrict__ out
 
 // scatter into Morton order; `fill` is a zeroed per-cell cursor
 template <int DIM>
-__global__ __launch_bounds__(GB) void scatter_kernel(const double *__restrict__ tgt, const uint32_t *__restrict__ code,
+__global__ __launch_bounds__(GB) void scatter_kernel(const double *__restrict__ tgt, uint32_t *code,
                                                     int64_t m, const uint32_t *__restrict__ start, uint32_t *__restrict__ fill,
                                                     double *__restrict__ spts, int32_t *__restrict__ sidx,
                                                     double4 *__restrict__ recs) {
@@ -229,6 +229,7 @@ __global__ __launch_bounds__(GB) void scatter_kernel(const double *__restrict__ 
 #pragma unroll
     for (int a = 0; a < DIM; ++a) spts[(int64_t)pos * DIM + a] = tgt[i * DIM + a];
     sidx[pos] = (int32_t)i;
+    code[i] = pos;  // the cell code is spent: the array becomes the inverse permutation (GridBuild::inv)
 }
 
 __device__ __forceinline__ bool better2(double da, int32_t ia, double db, int32_t ib) {
@@ -249,10 +250,11 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                                                        const int32_t *__restrict__ qorder,
                                                        const double4 *__restrict__ recs,
                                                        const uint32_t *__restrict__ start, GridParams gp,
-                                                       const double *__restrict__ thr_in, int32_t *__restrict__ idx_out,
+                                                       const double *__restrict__ thr_in, int32_t *idx_out,
                                                        double *__restrict__ d2_out, const int32_t *__restrict__ done,
                                                        long long *__restrict__ dbg, int cap,
-                                                       Deferred *__restrict__ deferred, uint32_t *__restrict__ n_deferred) {
+                                                       Deferred *__restrict__ deferred, uint32_t *__restrict__ n_deferred,
+                                                       const int32_t *hint, const uint32_t *__restrict__ inv, uint32_t m) {
     if (done && *done) return;
     const int64_t t = (int64_t)blockIdx.x * QB + threadIdx.x;
     if (t >= n) return;
@@ -327,6 +329,14 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         }
     };
 
+    // ICP_HINT_IDX: a target the caller already knows (last iteration's match) is an ordinary candidate,
+    // evaluated first.  Its distance prunes most neighbour cells at once; the answer is unchanged because
+    // every cell that could hold a better or tying point is still visited.  (hint may alias idx_out:
+    // each lane reads its entry here and writes it at the very end.)
+    if (hint) {
+        const uint32_t h = (uint32_t)hint[q];
+        if (h < m) eval(recs[inv[h]]);
+    }
     for (int l = 0; l <= gp.bits; ++l) {
         if (l >= cap) {
             // A few queries (sparse regions, far outliers) need many levels and would hold their whole
@@ -705,10 +715,12 @@ int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBui
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, bsum, (int)nsb);
     hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nsb), dim3(GB), 0, st, gb.start, (const uint32_t *)bsum, ncell, (uint32_t)m);
     ICP_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(uint32_t), st));
-    if (dim == 3) hipLaunchKernelGGL(scatter_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, (const uint32_t *)codes, m, (const uint32_t *)gb.start, count, gb.spts, gb.sidx, (double4 *)gb.recs);
-    else hipLaunchKernelGGL(scatter_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, (const uint32_t *)codes, m, (const uint32_t *)gb.start, count, gb.spts, gb.sidx, (double4 *)gb.recs);
+    if (dim == 3) hipLaunchKernelGGL(scatter_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, (const uint32_t *)gb.start, count, gb.spts, gb.sidx, (double4 *)gb.recs);
+    else hipLaunchKernelGGL(scatter_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, (const uint32_t *)gb.start, count, gb.spts, gb.sidx, (double4 *)gb.recs);
     ICP_HIP_CHECK(hipGetLastError());
     gb.gp = gp;
+    gb.inv = codes;
+    gb.m = m;
     gb.usable = true;
     return ICP_OK;
 }
@@ -717,7 +729,7 @@ long long *g_grid_dbg = nullptr;    // per-lane instrumentation (ICP_GRID_DEBUG 
 hipEvent_t *g_grid_events = nullptr;  // [3]: before the per-lane pass, between the passes, after the deferred pass
 
 int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
-               const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done) {
+               const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done, const int32_t *hint) {
     hipStream_t st = ctx->stream;
     // levels the per-lane pass handles itself (ICP_GRID_CAP=0: all of them, single pass)
     static const int cap_env = getenv("ICP_GRID_CAP") ? atoi(getenv("ICP_GRID_CAP")) : 1;
@@ -732,7 +744,8 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
     do { \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[0], st); \
         hipLaunchKernelGGL((grid_query_kernel<D, L, 256, 4>), dim3(nb), dim3(256), 0, st, src, n, qorder, (const double4 *)gb.recs, \
-                           (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, g_grid_dbg, cap, dlist, ndef); \
+                           (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, g_grid_dbg, cap, dlist, ndef, hint, \
+                           (const uint32_t *)gb.inv, (uint32_t)gb.m); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[1], st); \
         if (cap < 1000) \
             hipLaunchKernelGGL((grid_defer_kernel<D, L>), dim3(nb2), dim3(64), 0, st, src, (const double4 *)gb.recs, \

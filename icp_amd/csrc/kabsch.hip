@@ -608,7 +608,10 @@ extern "C" int icp_rigid_run(icp_ctx *ctx, const double *src, int64_t n, const d
     ICP_HIP_CHECK(hipMemcpyAsync(ss, src, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToDevice, s));  // icp_3d.py:104
     const int32_t *done = &st->done;
     for (int it = 0; it < max_iter; ++it) {
-        if (int rc = closest_dispatch(ctx, ss, n, tgt, m, dim, flags, idx, nullptr, done, &grid)) return rc;
+        // from the second iteration on, idx holds the previous correspondences: a tight starting bound
+        if (int rc = closest_dispatch(ctx, ss, n, tgt, m, dim, it > 0 ? (flags | ICP_HINT_IDX) : (flags & ~(unsigned)ICP_HINT_IDX), idx,
+                                      nullptr, done, &grid))
+            return rc;
         int nb = 0;
         const double *part = (const double *)ctx->partials.ptr;
         if (int rc = shard_sums(ctx, src, tgt, idx, n, dim, st->cs, st->ct, st->sums, done, &nb)) return rc;

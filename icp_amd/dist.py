@@ -66,8 +66,11 @@ class GpuOps:
         return src
 
     def closest(self, ss, tgt, idx):
+        # from the second call on, idx still holds the previous correspondences: hand them in as hints
+        flags = self.flags | (_lib.ICP_HINT_IDX if getattr(self, "_warm", None) is idx else 0)
+        self._warm = idx
         if getattr(self, "_target", None) is not None:
-            self.ctx.call_fast("icp_closest_target", self._target, ptr(ss), ss.shape[0], self.flags, ptr(idx), ptr(None))
+            self.ctx.call_fast("icp_closest_target", self._target, ptr(ss), ss.shape[0], flags, ptr(idx), ptr(None))
         else:
             self.ctx.call_fast("icp_closest", ptr(ss), ss.shape[0], ptr(tgt), tgt.shape[0], ss.shape[1], self.flags,
                           ptr(idx), ptr(None))

@@ -24,21 +24,23 @@ def _dims(ctx, src, tgt=None):
 
 
 def closest_indices(source, target, compare_sqrt=False, want_d2=False, force_brute=False, force_grid=False,
-                    ctx=None):
+                    ctx=None, hint=None):
     """idx[i] = argmin_j |target[j]-source[i]|^2 (bit-exact reference arithmetic,
-    lowest index on ties).  Returns int32 tensor (and the fp64 d2 tensor)."""
+    lowest index on ties).  Returns int32 tensor (and the fp64 d2 tensor).
+    hint: optional int32 indices (e.g. the previous iteration's result) used as the grid
+    search's starting bound (ICP_HINT_IDX); the result does not depend on them."""
     ctx = ctx or get_context()
     torch = ctx.torch
     src, tgt, dim = _dims(ctx, source, target)
     n, m = src.shape[0], tgt.shape[0]
     if m == 0:
         raise ValueError("attempt to get argmin of an empty sequence")  # numpy's message
-    idx = ctx.empty((n,), torch.int32)
+    idx = ctx.empty((n,), torch.int32) if hint is None else ctx.to_dev(hint, torch.int32).clone()
     d2 = ctx.empty((n,), torch.float64) if want_d2 else None
     if n == 0:      # Match over an empty source: nothing to launch (empty tensors have no storage)
         return (idx, d2) if want_d2 else idx
     flags = ((_lib.ICP_COMPARE_SQRT if compare_sqrt else 0) | (_lib.ICP_FORCE_BRUTE if force_brute else 0) |
-             (_lib.ICP_FORCE_GRID if force_grid else 0))
+             (_lib.ICP_FORCE_GRID if force_grid else 0) | (_lib.ICP_HINT_IDX if hint is not None else 0))
     ctx.call("icp_closest", ptr(src), n, ptr(tgt), m, dim, flags, ptr(idx), ptr(d2))
     return (idx, d2) if want_d2 else idx
 

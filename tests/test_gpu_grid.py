@@ -131,3 +131,24 @@ def test_sharded_ops_single_process(rigid):
     assert len(hist) == n
     np.testing.assert_allclose(T, r["T"].cpu().numpy(), rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(hist, r["err_hist"].cpu().numpy()[:n], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["normal3", "uniform2", "clustered_outside", "lattice_ties"])
+def test_hint_does_not_change_the_result(rigid, name):
+    """ICP_HINT_IDX: whatever indices come in -- the true answer, random targets, a constant,
+    out-of-range garbage -- the result is the same exact argmin (also with ICP_COMPARE_SQRT)."""
+    src, tgt = clouds()[name]
+    n, m = len(src), len(tgt)
+    rng = np.random.default_rng(5)
+    ref_i, ref_d = rigid.closest_indices(src, tgt, want_d2=True, force_brute=True)
+    ref_i, ref_d = ref_i.cpu().numpy(), ref_d.cpu().numpy()
+    hints = {"truth": ref_i, "random": rng.integers(0, m, n).astype(np.int32), "zero": np.zeros(n, np.int32),
+             "garbage": np.where(rng.random(n) < 0.5, -7, m + 12345).astype(np.int32),
+             "mixed": np.where(rng.random(n) < 0.5, ref_i, rng.integers(-5, m + 5, n)).astype(np.int32)}
+    for k, h in hints.items():
+        gi, gd = rigid.closest_indices(src, tgt, want_d2=True, force_grid=True, hint=h)
+        assert np.array_equal(gi.cpu().numpy(), ref_i), (name, k)
+        assert np.array_equal(gd.cpu().numpy(), ref_d), (name, k)
+    si = rigid.closest_indices(src, tgt, force_grid=True, compare_sqrt=True).cpu().numpy()
+    sh = rigid.closest_indices(src, tgt, force_grid=True, compare_sqrt=True, hint=hints["random"]).cpu().numpy()
+    assert np.array_equal(si, sh)
