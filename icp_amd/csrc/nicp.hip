@@ -2023,10 +2023,18 @@ extern "C" int nicp_run(icp_ctx *ctx, nicp_graph *g, double *P_inout, const doub
     int32_t *idx = (int32_t *)(nn + n * dim);
     double err = 100000000.0;  // nicp_3d.py:346
     int it = 0;
+    // the target does not change: one search index for every outer iteration, and from the second
+    // iteration on the previous correspondences go in as starting bounds
+    GridBuild grid;
+    const bool indexed = grid_worthwhile(n, m, 0u);
+    if (indexed)
+        if (int rc = grid_build(ctx, tgt, m, dim, grid)) return rc;
     for (; it < max_outer; ++it) {
         const double e = err;
         if (int rc = nicp_deform(ctx, g, P_inout, v, dd)) return rc;
-        if (int rc = closest_dispatch(ctx, dd, n, tgt, m, dim, 0u, idx, nullptr, nullptr, nullptr)) return rc;
+        if (int rc = closest_dispatch(ctx, dd, n, tgt, m, dim, it > 0 ? (unsigned)ICP_HINT_IDX : 0u, idx, nullptr, nullptr,
+                                      indexed ? &grid : nullptr))
+            return rc;
         if (int rc = icp_gather_points(ctx, tgt, idx, n, dim, nn)) return rc;
         nicp_solve_stats st;
         if (int rc = nicp_solve(ctx, g, P_inout, v, nn, c3_inout_host, flags, opts_host, &st)) return rc;
