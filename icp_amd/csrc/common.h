@@ -88,6 +88,8 @@ int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *t
                      unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done,
                      const GridBuild *grid = nullptr);
 bool grid_worthwhile(int64_t n, int64_t m, unsigned flags);
+// exact k nearest (k = 6 or 8) by the key fl(sqrt(d2)), ties to the lower index, through a built grid
+int grid_knn(icp_ctx *ctx, const GridBuild &gb, const double *q, int64_t nq, int k, int32_t *idx_out, double *dist_out);
 
 // 64-bit shuffle helpers (wave = 64 lanes)
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {

@@ -639,6 +639,147 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double *__restrict
     }
 }
 
+// ------------------------------------------------------------------ exact k nearest through the grid
+// KNN of nicp_3d.py:53-57 / nicp3d.cpp:100-137: the k smallest keys fl(sqrt(d2)), ties to the lower
+// index.  One query per lane, a sorted list of K (key, index) pairs in registers.  Level by level the
+// 3^DIM neighbourhood of the query's cell is scanned from scratch (a restart, so no record is ever
+// inserted twice); a cell is skipped when fl(sqrt(bound)) > k-th key and the search ends when the
+// k-th key is strictly below fl(sqrt(gap^2)): sqrt and its rounding are monotone, so every unvisited
+// record has a key >= that, and an equal key would still have to be looked at for its index.
+template <int DIM, int K>
+__global__ __launch_bounds__(GB) void grid_knn_kernel(const double *__restrict__ qpts, int64_t nq,
+                                                     const double4 *__restrict__ recs, const uint32_t *__restrict__ start,
+                                                     GridParams gp, int32_t *__restrict__ idx_out, double *__restrict__ dist_out) {
+    const int64_t t = (int64_t)blockIdx.x * GB + threadIdx.x;
+    if (t >= nq) return;
+    double s[DIM];
+    bool finite = true;
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) {
+        s[a] = qpts[t * DIM + a];
+        finite = finite && fabs(s[a]) < __builtin_inf();
+    }
+    double key[K];
+    int32_t id[K];
+    auto reset = [&]() {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            key[k] = __builtin_inf();
+            id[k] = 0x7fffffff;
+        }
+    };
+    reset();
+    if (finite) {
+        int c0[DIM];
+        cell_of<DIM>(s, gp, c0);
+        constexpr int NBR = DIM == 3 ? 27 : 9;
+        for (int l = 0; l <= gp.bits; ++l) {
+            reset();
+            double gate = __builtin_inf();
+            const double hl = gp.h * (double)(1 << l);
+            const int ncl = 1 << (gp.bits - l);
+            const double slack_h = hl * 0x1p-20;
+            int cl[DIM];
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) cl[a] = c0[a] >> l;
+            for (int step = 0; step < NBR; ++step) {
+                // own cell first: it fills the list and makes the bound test bite
+                const int nb = step == 0 ? NBR / 2 : (step <= NBR / 2 ? step - 1 : step);
+                const int off[3] = {nb % 3 - 1, (nb / 3) % 3 - 1, nb / 9 - 1};
+                bool inside = true;
+                double bound = 0.0;
+                int x[DIM];
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) {
+                    x[a] = cl[a] + off[a];
+                    inside = inside && x[a] >= 0 && x[a] < ncl;
+                    const double sl = slack_h + (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
+                    const double lo = gp.mn[a] + (double)x[a] * hl, hi = gp.mn[a] + (double)(x[a] + 1) * hl;
+                    double g = lo - s[a] - sl;
+                    const double gh = s[a] - hi - sl;
+                    g = gh > g ? gh : g;
+                    g = g > 0.0 ? g : 0.0;
+                    bound = bound + g * g;
+                }
+                if (!inside) continue;
+                if (__dsqrt_rn(bound) > key[K - 1]) continue;
+                const uint32_t code = morton<DIM>(x);
+                const uint32_t p0 = start[(uint64_t)code << (DIM * l)], p1 = start[((uint64_t)code + 1) << (DIM * l)];
+                for (uint32_t p = p0; p < p1; ++p) {
+                    const double4 rc = recs[p];
+                    double d2 = 0.0;
+                    {
+                        const double dx = rc.x - s[0], dy = rc.y - s[1];
+                        d2 += dx * dx;
+                        d2 += dy * dy;
+                        if (DIM == 3) {
+                            const double dz = rc.z - s[DIM - 1];
+                            d2 += dz * dz;
+                        }
+                    }
+                    if (!(d2 <= gate)) continue;
+                    const double r = __dsqrt_rn(d2);
+                    const int32_t jj = (int32_t)__double_as_longlong(rc.w);
+                    if (!(r < key[K - 1] || (r == key[K - 1] && jj < id[K - 1]))) continue;
+                    double ck = r;
+                    int32_t ci = jj;
+                    bool shifting = false;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const bool sw = shifting || ck < key[k] || (ck == key[k] && ci < id[k]);
+                        shifting = sw;
+                        const double tk = sw ? key[k] : ck;
+                        const int32_t ti = sw ? id[k] : ci;
+                        key[k] = sw ? ck : key[k];
+                        id[k] = sw ? ci : id[k];
+                        ck = tk;
+                        ci = ti;
+                    }
+                    const double kr = key[K - 1];
+                    // gate >= every d2 whose rounded root is <= kr.  Records arrive in no particular index
+                    // order here, so an EQUAL root must get through too (it may carry a lower index): the
+                    // class of d2 values that round to kr ends below kr^2 (1 + 2^-52), hence the margin.
+                    gate = (kr > 1e-150 && kr < 1e150) ? kr * kr * (1.0 + 0x1p-50) : __builtin_inf();
+                }
+            }
+            if (ncl == 1) break;
+            double mgap = __builtin_inf();
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) {
+                const double sl = slack_h + (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
+                if (cl[a] - 1 > 0) {
+                    const double g = s[a] - (gp.mn[a] + (double)(cl[a] - 1) * hl) - sl;
+                    mgap = g < mgap ? g : mgap;
+                }
+                if (cl[a] + 2 < ncl) {
+                    const double g = (gp.mn[a] + (double)(cl[a] + 2) * hl) - s[a] - sl;
+                    mgap = g < mgap ? g : mgap;
+                }
+            }
+            if (mgap == __builtin_inf()) break;
+            if (mgap > 0.0 && key[K - 1] < __dsqrt_rn(mgap * mgap)) break;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        idx_out[t * K + k] = id[k];
+        dist_out[t * K + k] = key[k];
+    }
+}
+
+int grid_knn(icp_ctx *ctx, const GridBuild &gb, const double *q, int64_t nq, int k, int32_t *idx_out, double *dist_out) {
+    const unsigned nb = (unsigned)((nq + GB - 1) / GB);
+    hipStream_t st = ctx->stream;
+    const double4 *recs = (const double4 *)gb.recs;
+    const uint32_t *start = (const uint32_t *)gb.start;
+    if (gb.gp.dim == 3 && k == 6) hipLaunchKernelGGL((grid_knn_kernel<3, 6>), dim3(nb), dim3(GB), 0, st, q, nq, recs, start, gb.gp, idx_out, dist_out);
+    else if (gb.gp.dim == 3) hipLaunchKernelGGL((grid_knn_kernel<3, 8>), dim3(nb), dim3(GB), 0, st, q, nq, recs, start, gb.gp, idx_out, dist_out);
+    else if (k == 6) hipLaunchKernelGGL((grid_knn_kernel<2, 6>), dim3(nb), dim3(GB), 0, st, q, nq, recs, start, gb.gp, idx_out, dist_out);
+    else hipLaunchKernelGGL((grid_knn_kernel<2, 8>), dim3(nb), dim3(GB), 0, st, q, nq, recs, start, gb.gp, idx_out, dist_out);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
 // ------------------------------------------------------------------ host side
 static int env_bits() {
     const char *e = getenv("ICP_GRID_BITS");

@@ -20,6 +20,7 @@
 //   Q7 (2-D) b-columns of the fit block carry no weight factor.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -1619,6 +1620,15 @@ extern "C" int nicp_knn(icp_ctx *ctx, const double *v, int64_t n, int dim, const
     ICP_REQUIRE(n >= k, "fewer points than k (nicp3d.cpp:130-135 pops an empty heap; refused here)");
     if (nq == 0) return ICP_OK;
     ICP_HIP_CHECK(hipSetDevice(ctx->device));
+    {   // large point sets: the exact grid search (same keys, same tie rule); ICP_KNN_GRID_MIN moves the switch
+        const char *e = getenv("ICP_KNN_GRID_MIN");
+        const long long gmin = e ? atoll(e) : 8192;
+        if (n >= gmin && nq >= 256) {
+            GridBuild gb;
+            if (int rc = grid_build(ctx, v, n, dim, gb)) return rc;
+            if (gb.usable) return grid_knn(ctx, gb, q, nq, k, idx_out, dist_out);  // non-finite points: full scan below
+        }
+    }
     const unsigned nb = (unsigned)((nq + NB - 1) / NB);
     hipStream_t st = ctx->stream;
     if (dim == 3 && k == 6) hipLaunchKernelGGL((knn_rows_kernel<3, 6>), dim3(nb), dim3(NB), 0, st, v, n, q, nq, idx_out, dist_out);

@@ -206,3 +206,34 @@ def test_solve_10k_mesh_properties(mods):
     P2, st2 = nic.solve(P0, w, v, edges, nn, C, compat=False, opts=opts)
     assert st1["err"] < st1["err0"]
     assert torch.equal(P1, P2) and st1 == st2
+
+
+@pytest.mark.parametrize("kind", ["mesh", "clusters_dups", "plane2d", "line"])
+def test_knn_grid_equals_full_scan(mods, kind, monkeypatch):
+    """The grid-accelerated KNN (large point sets) returns the same indices and the same fp64 keys
+    as the full-scan kernel: meshes, clustered clouds with exact duplicates (ties -> lower index),
+    2-D points and a degenerate line."""
+    nic = mods["nicp"]
+    rng = np.random.default_rng(11)
+    if kind == "mesh":
+        v = orc.make_grid_mesh(150, 120, seed=3)[0]
+    elif kind == "clusters_dups":
+        base = np.concatenate([rng.standard_normal((3000, 3)) * 0.02 + c for c in rng.uniform(-3, 3, (5, 3))])
+        v = np.concatenate([base, base[rng.permutation(len(base))[:4000]], np.round(base[:3000], 1)])
+    elif kind == "plane2d":
+        v = rng.uniform(-1, 1, (20000, 2))
+    else:
+        v = np.zeros((12000, 3))
+        v[:, 0] = np.round(rng.uniform(0, 1, 12000), 3)      # many coincident points
+    q = np.concatenate([v[::7], v[:50] + 10.0, rng.uniform(v.min(), v.max(), (500, v.shape[1]))])
+    for k in (6, 8):
+        monkeypatch.setenv("ICP_KNN_GRID_MIN", "1")
+        gi, gd = nic.knn(v, q, k)
+        monkeypatch.setenv("ICP_KNN_GRID_MIN", "1000000000")
+        bi, bd = nic.knn(v, q, k)
+        assert np.array_equal(gi.cpu().numpy(), bi.cpu().numpy()), (kind, k)
+        assert np.array_equal(gd.cpu().numpy(), bd.cpu().numpy()), (kind, k)
+    monkeypatch.setenv("ICP_KNN_GRID_MIN", "1")
+    si, sd = nic.knn(v, v, 6)                       # the Initialise case: every point against the set itself
+    oi, od = c_oracle.knn_rows(v, 6)
+    assert np.array_equal(si.cpu().numpy(), oi) and np.array_equal(sd.cpu().numpy(), od)
