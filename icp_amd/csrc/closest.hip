@@ -351,9 +351,10 @@ int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *t
         grid = &local;
     }
     const bool use_grid = grid && grid->usable && !(flags & ICP_FORCE_BRUTE);
+    const bool pos_mode = use_grid && (flags & ICP_INTERNAL_POS);
     auto argmin = [&](double *d2) -> int {
         if (use_grid) return grid_query(ctx, *grid, src, n, nullptr, false, nullptr, idx_out, d2, done,
-                                        (flags & ICP_HINT_IDX) ? idx_out : nullptr);
+                                        (flags & ICP_HINT_IDX) ? idx_out : nullptr, pos_mode);
         return dim == 3 ? launch_closest<3, false>(ctx, src, n, tgt, m, nullptr, idx_out, d2, done)
                         : launch_closest<2, false>(ctx, src, n, tgt, m, nullptr, idx_out, d2, done);
     };
@@ -366,7 +367,7 @@ int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *t
     hipLaunchKernelGGL(sqrt_class_upper, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dmin, n, thr);
     ICP_HIP_CHECK(hipGetLastError());
     int rc;
-    if (use_grid) rc = grid_query(ctx, *grid, src, n, nullptr, true, thr, idx_out, nullptr, done);
+    if (use_grid) rc = grid_query(ctx, *grid, src, n, nullptr, true, thr, idx_out, nullptr, done, nullptr, pos_mode);
     else rc = dim == 3 ? launch_closest<3, true>(ctx, src, n, tgt, m, thr, idx_out, nullptr, done)
                        : launch_closest<2, true>(ctx, src, n, tgt, m, thr, idx_out, nullptr, done);
     if (rc) return rc;

@@ -83,7 +83,12 @@ int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &g
 int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, Scratch &sa, Scratch &sb,
                     Scratch &sc, Scratch &sd);
 int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
-               const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done, const int32_t *hint = nullptr);
+               const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done, const int32_t *hint = nullptr,
+               bool pos_mode = false);
+// internal flag of closest_dispatch: correspondences (and hints) are SORTED POSITIONS into GridBuild::spts /
+// sidx instead of original indices (icp_rigid_run keeps them that way between iterations: the gathers of the
+// reduction kernels then walk the Morton-sorted copy almost sequentially)
+constexpr unsigned ICP_INTERNAL_POS = 0x10000u;
 int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
                      unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done,
                      const GridBuild *grid = nullptr);

@@ -241,7 +241,8 @@ __device__ __forceinline__ bool better2(double da, int32_t ia, double db, int32_
 // LE = false: argmin (d2, index).  LE = true: lowest index with d2 <= thr[q].
 // A query the per-lane pass gave up on after `cap` levels: state to resume from
 struct Deferred {
-    int32_t q, level, bi, pad;
+    int32_t q, level, bi;
+    uint32_t bp;  // sorted position of the best record so far
     double best;
 };
 
@@ -254,7 +255,8 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                                                        double *__restrict__ d2_out, const int32_t *__restrict__ done,
                                                        long long *__restrict__ dbg, int cap,
                                                        Deferred *__restrict__ deferred, uint32_t *__restrict__ n_deferred,
-                                                       const int32_t *hint, const uint32_t *__restrict__ inv, uint32_t m) {
+                                                       const int32_t *hint, const uint32_t *__restrict__ inv, uint32_t m,
+                                                       int pos_mode) {
     if (done && *done) return;
     const int64_t t = (int64_t)blockIdx.x * QB + threadIdx.x;
     if (t >= n) return;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             isnan = isnan || s[a] != s[a];
         }
         if (!finite) {
-            idx_out[q] = 0;
+            idx_out[q] = pos_mode ? (int32_t)inv[0] : 0;
             if (d2_out) d2_out[q] = LE ? __builtin_inf() : (isnan ? __builtin_nan("") : __builtin_inf());
             return;
         }
@@ -301,7 +303,8 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     __shared__ float wlb[LIST][QB];  // lower bound of each listed cell (rounded down)
     const int lane_slot = threadIdx.x;
 
-    auto eval = [&](const double4 &rc) {
+    uint32_t bp = 0;  // sorted position of the best record (what pos_mode returns instead of its index)
+    auto eval = [&](const double4 &rc, uint32_t pos) {
         const double dx = rc.x - s[0], dy = rc.y - s[1];
         double d = dx * dx + dy * dy;
         if (DIM == 3) {
@@ -312,11 +315,13 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         if (LE) {
             if (d <= thr && id < bi) {
                 bi = id;
+                bp = pos;
                 best = 0.0;
             }
         } else if (d < best || (d == best && id < bi)) {
             best = d;
             bi = id;
+            bp = pos;
         }
     };
     auto scan = [&](uint32_t p0, uint32_t p1) {
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 #pragma unroll
             for (int u = 0; u < 4; ++u) rc[u] = recs[p + u < p1 ? p + u : p1 - 1];  // re-reads are idempotent
 #pragma unroll
-            for (int u = 0; u < 4; ++u) eval(rc[u]);
+            for (int u = 0; u < 4; ++u) eval(rc[u], p + u < p1 ? p + u : p1 - 1);
         }
     };
 
@@ -335,7 +340,10 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     // each lane reads its entry here and writes it at the very end.)
     if (hint) {
         const uint32_t h = (uint32_t)hint[q];
-        if (h < m) eval(recs[inv[h]]);
+        if (h < m) {
+            const uint32_t hp = pos_mode ? h : inv[h];   // pos_mode: hints are sorted positions too
+            eval(recs[hp], hp);
+        }
     }
     for (int l = 0; l <= gp.bits; ++l) {
         if (l >= cap) {
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             dq.q = (int32_t)q;
             dq.level = l;
             dq.bi = bi;
-            dq.pad = 0;
+            dq.bp = bp;
             dq.best = best;
             deferred[slot] = dq;
             return;
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 #pragma unroll
                     for (int u = 0; u < UNR; ++u) rc[u] = recs[p + u < pe ? p + u : pe - 1];
 #pragma unroll
-                    for (int u = 0; u < UNR; ++u) eval(rc[u]);
+                    for (int u = 0; u < UNR; ++u) eval(rc[u], p + u < pe ? p + u : pe - 1);
                     p += UNR;
                     dbg_cand += UNR;
                 }
@@ -494,8 +502,11 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         dbg[t * 3 + 1] = dbg_levels;
         dbg[t * 3 + 2] = dbg_cand;
     }
-    if (bi == 0x7fffffff) bi = 0;  // nothing comparable found (e.g. every d2 = +inf): np.argmin -> 0
-    idx_out[q] = bi;
+    if (bi == 0x7fffffff) {  // nothing comparable found (e.g. every d2 = +inf): np.argmin -> 0
+        bi = 0;
+        bp = inv[0];
+    }
+    idx_out[q] = pos_mode ? (int32_t)bp : bi;
     if (d2_out) d2_out[q] = best;
 }
 
@@ -508,7 +519,8 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double *__restrict
                                                         const double *__restrict__ thr_in, int32_t *__restrict__ idx_out,
                                                         double *__restrict__ d2_out, const int32_t *__restrict__ done,
                                                         const Deferred *__restrict__ deferred,
-                                                        const uint32_t *__restrict__ n_deferred) {
+                                                        const uint32_t *__restrict__ n_deferred,
+                                                        const uint32_t *__restrict__ inv, int pos_mode) {
     if (done && *done) return;
     constexpr int NBR = DIM == 3 ? 27 : 9;
     // one wave per block: __syncthreads() below is a wave-level fence, and the trip count is block-uniform
@@ -526,6 +538,7 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double *__restrict
         cell_of<DIM>(s, gp, c0);
         double best = dq.best;     // wave-uniform between levels
         int32_t bi = dq.bi;
+        uint32_t bp = dq.bp;
         const double thr = LE ? thr_in[q] : 0.0;
         for (int l = dq.level; l <= gp.bits; ++l) {
             const double hl = gp.h * (double)(1 << l);
@@ -575,12 +588,14 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double *__restrict
             const uint32_t total = pre_s[wv][NBR];
             double lb = best;
             int32_t li = bi;
+            uint32_t lp = bp;
             for (uint32_t tpos = lane; tpos < total; tpos += 64) {
                 int c = 0;  // last cell with pre[c] <= tpos
 #pragma unroll
                 for (int stp = 16; stp > 0; stp >>= 1)
                     if (c + stp < NBR && pre_s[wv][c + stp] <= tpos) c += stp;
-                const double4 rc = recs[r0_s[wv][c] + (tpos - pre_s[wv][c])];
+                const uint32_t rpos = r0_s[wv][c] + (tpos - pre_s[wv][c]);
+                const double4 rc = recs[rpos];
                 const double dx = rc.x - s[0], dy = rc.y - s[1];
                 double d = dx * dx + dy * dy;
                 if (DIM == 3) {
@@ -591,25 +606,30 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double *__restrict
                 if (LE) {
                     if (d <= thr && id < li) {
                         li = id;
+                        lp = rpos;
                         lb = 0.0;
                     }
                 } else if (d < lb || (d == lb && id < li)) {
                     lb = d;
                     li = id;
+                    lp = rpos;
                 }
             }
-            // wave argmin of (d2, index)
+            // wave argmin of (d2, index); the position rides along
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const double ob = shfl_xor_f64(lb, o);
                 const int32_t oi = __shfl_xor(li, o, 64);
+                const uint32_t op = (uint32_t)__shfl_xor((int)lp, o, 64);
                 if (ob < lb || (ob == lb && oi < li)) {
                     lb = ob;
                     li = oi;
+                    lp = op;
                 }
             }
             best = lb;
             bi = li;
+            bp = lp;
             __syncthreads();  // the next level rewrites pre_s / r0_s
             if (ncl == 1) break;
             double mgap = __builtin_inf();
@@ -632,8 +652,11 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double *__restrict
             }
         }
         if (lane == 0) {
-            if (bi == 0x7fffffff) bi = 0;
-            idx_out[q] = bi;
+            if (bi == 0x7fffffff) {
+                bi = 0;
+                bp = inv[0];
+            }
+            idx_out[q] = pos_mode ? (int32_t)bp : bi;
             if (d2_out) d2_out[q] = best;
         }
     }
@@ -870,7 +893,7 @@ long long *g_grid_dbg = nullptr;    // per-lane instrumentation (ICP_GRID_DEBUG 
 hipEvent_t *g_grid_events = nullptr;  // [3]: before the per-lane pass, between the passes, after the deferred pass
 
 int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
-               const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done, const int32_t *hint) {
+               const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done, const int32_t *hint, bool pos_mode) {
     hipStream_t st = ctx->stream;
     // levels the per-lane pass handles itself (ICP_GRID_CAP=0: all of them, single pass)
     static const int cap_env = getenv("ICP_GRID_CAP") ? atoi(getenv("ICP_GRID_CAP")) : 1;
@@ -886,12 +909,12 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
         if (g_grid_events) (void)hipEventRecord(g_grid_events[0], st); \
         hipLaunchKernelGGL((grid_query_kernel<D, L, 256, 4>), dim3(nb), dim3(256), 0, st, src, n, qorder, (const double4 *)gb.recs, \
                            (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, g_grid_dbg, cap, dlist, ndef, hint, \
-                           (const uint32_t *)gb.inv, (uint32_t)gb.m); \
+                           (const uint32_t *)gb.inv, (uint32_t)gb.m, pos_mode ? 1 : 0); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[1], st); \
         if (cap < 1000) \
             hipLaunchKernelGGL((grid_defer_kernel<D, L>), dim3(nb2), dim3(64), 0, st, src, (const double4 *)gb.recs, \
                                (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (const Deferred *)dlist, \
-                               (const uint32_t *)ndef); \
+                               (const uint32_t *)ndef, (const uint32_t *)gb.inv, pos_mode ? 1 : 0); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
     } while (0)
     if (gb.gp.dim == 3) {

@@ -334,11 +334,16 @@ __global__ void gather_kernel(const double *__restrict__ tgt, const int32_t *__r
     for (int c = 0; c < DIM; ++c) out[i * DIM + c] = tgt[j * DIM + c];
 }
 
-// idx_out[order[i]] = idx_sorted[i]: undo the Morton ordering of the queries
-__global__ void unsort_idx_kernel(const int32_t *__restrict__ idx_sorted, const int32_t *__restrict__ order, int64_t n,
-                                  int32_t *__restrict__ idx_out) {
+// idx_out[order[i]] = idx_sorted[i]: undo the Morton ordering of the queries (order may be null) and,
+// when the loop kept sorted target positions instead of indices, translate them (sidx non-null).
+// In place (idx_out == idx_sorted) only without `order`.
+__global__ void unsort_idx_kernel(const int32_t *idx_sorted, const int32_t *__restrict__ order,
+                                  const int32_t *__restrict__ sidx, int64_t n, int32_t *idx_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) idx_out[order[i]] = idx_sorted[i];
+    if (i < n) {
+        const int32_t v = idx_sorted[i];
+        idx_out[order ? order[i] : i] = sidx ? sidx[v] : v;
+    }
 }
 
 __global__ void rigid_init_kernel(RigidState *st) {
@@ -607,23 +612,29 @@ extern "C" int icp_rigid_run(icp_ctx *ctx, const double *src, int64_t n, const d
     if (int rc = column_sums(ctx, tgt, m, dim, st->ct, 1)) return rc;
     ICP_HIP_CHECK(hipMemcpyAsync(ss, src, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToDevice, s));  // icp_3d.py:104
     const int32_t *done = &st->done;
+    // With the grid, correspondences stay SORTED TARGET POSITIONS inside the loop: the reductions then
+    // gather from the Morton-sorted copy of the target (queries are in Morton order too, so neighbouring
+    // lanes read neighbouring records) and last iteration's position is the next search's hint directly.
+    const bool pos = grid.usable && !(flags & ICP_FORCE_BRUTE);
+    const double *tgt_rows = pos ? grid.spts : tgt;
+    flags = (flags & ~(unsigned)ICP_HINT_IDX) | (pos ? ICP_INTERNAL_POS : 0u);
     for (int it = 0; it < max_iter; ++it) {
         // from the second iteration on, idx holds the previous correspondences: a tight starting bound
-        if (int rc = closest_dispatch(ctx, ss, n, tgt, m, dim, it > 0 ? (flags | ICP_HINT_IDX) : (flags & ~(unsigned)ICP_HINT_IDX), idx,
-                                      nullptr, done, &grid))
+        if (int rc = closest_dispatch(ctx, ss, n, tgt, m, dim, it > 0 ? (flags | ICP_HINT_IDX) : flags, idx, nullptr, done, &grid))
             return rc;
         int nb = 0;
         const double *part = (const double *)ctx->partials.ptr;
-        if (int rc = shard_sums(ctx, src, tgt, idx, n, dim, st->cs, st->ct, st->sums, done, &nb)) return rc;
+        if (int rc = shard_sums(ctx, src, tgt_rows, idx, n, dim, st->cs, st->ct, st->sums, done, &nb)) return rc;
         part = (const double *)ctx->partials.ptr;
         if (dim == 3) hipLaunchKernelGGL(reduce_solve_kernel<3>, dim3(1), dim3(RB), 0, s, part, nb, (const double *)st->cs, (const double *)st->ct, st->sums, st->R, st->t, done);
         else hipLaunchKernelGGL(reduce_solve_kernel<2>, dim3(1), dim3(RB), 0, s, part, nb, (const double *)st->cs, (const double *)st->ct, st->sums, st->R, st->t, done);
-        if (int rc = apply_err(ctx, 1, src, tgt, idx, n, dim, st->R, st->t, ss, st->sums, done, &nb)) return rc;
+        if (int rc = apply_err(ctx, 1, src, tgt_rows, idx, n, dim, st->R, st->t, ss, st->sums, done, &nb)) return rc;
         hipLaunchKernelGGL(reduce_step_kernel, dim3(1), dim3(RB), 0, s, part, nb, st, tol, use_tol, err_hist_dev);
         ICP_HIP_CHECK(hipGetLastError());
     }
-    if (order && idx_out)
-        hipLaunchKernelGGL(unsort_idx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int32_t *)idx, order, n, idx_out);
+    if (idx_out && (order || pos))
+        hipLaunchKernelGGL(unsort_idx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int32_t *)idx, order,
+                           pos ? (const int32_t *)grid.sidx : (const int32_t *)nullptr, n, idx_out);
     hipLaunchKernelGGL(rigid_finish_kernel, dim3(1), dim3(1), 0, s, (const RigidState *)st, dim, T_out_dev, iters_out_dev);
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
