@@ -152,3 +152,22 @@ def test_hint_does_not_change_the_result(rigid, name):
     si = rigid.closest_indices(src, tgt, force_grid=True, compare_sqrt=True).cpu().numpy()
     sh = rigid.closest_indices(src, tgt, force_grid=True, compare_sqrt=True, hint=hints["random"]).cpu().numpy()
     assert np.array_equal(si, sh)
+
+
+@pytest.mark.parametrize("dim,compare_sqrt", [(2, False), (3, True), (2, True)])
+def test_grid_inside_icp_2d_and_sqrt(rigid, dim, compare_sqrt):
+    """The fused loop with the grid (sorted-position bookkeeping, hints) against the full-scan loop:
+    2-D clouds and the C++ comparison of rounded roots (second, `<= threshold` pass)."""
+    rng = np.random.default_rng(40 + dim)
+    tgt = rng.standard_normal((60000, dim))
+    c, s = np.cos(0.2), np.sin(0.2)
+    R = np.eye(dim)
+    R[:2, :2] = [[c, s], [-s, c]]
+    src = ((tgt - 0.05) @ R)[rng.permutation(len(tgt))[:45000]]
+    a = rigid.rigid_icp(src, tgt, 1e-3, 25, want_idx=True, force_grid=True, compare_sqrt=compare_sqrt)
+    b = rigid.rigid_icp(src, tgt, 1e-3, 25, want_idx=True, force_brute=True, compare_sqrt=compare_sqrt)
+    assert int(a["iters"].cpu()[0]) == int(b["iters"].cpu()[0])
+    assert np.array_equal(a["idx"].cpu().numpy(), b["idx"].cpu().numpy())
+    np.testing.assert_allclose(a["T"].cpu().numpy(), b["T"].cpu().numpy(), rtol=1e-12, atol=1e-13)
+    n = int(a["iters"].cpu()[0])
+    np.testing.assert_allclose(a["err_hist"].cpu().numpy()[:n], b["err_hist"].cpu().numpy()[:n], rtol=1e-11)
