@@ -133,3 +133,26 @@ def test_nicp_3d_main_on_files(tmp_path, capsys):
     np.testing.assert_array_equal(v_out, newPts)
     np.testing.assert_array_equal(e_out, edges)
     np.testing.assert_allclose(newPts, g["nicp_dd"], rtol=1e-4, atol=1e-4)   # the reference's own run (compat mode)
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line carrying the driver's contract fields plus `roofline` and
+    `cpu_baseline` (small cloud so the check is quick)."""
+    import json
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--n", "65536", "--cpu-sample", "2048"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 65536 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma", "valu") and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
