@@ -55,6 +55,9 @@ _SIGNATURES = {
     "nicp_knn_weights": [c_dp, c_dp, c_i64, c_int, c_int, c_dp, c_dp],
     "nicp_graph_create": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_i64, c_int, ctypes.POINTER(ctypes.c_void_p)],
     "nicp_graph_destroy": [c_dp, c_dp],
+    "nicp_set_weights": [c_dp, c_dp, c_dp, c_dp, c_dp],
+    "nicp_set_landmarks": [c_dp, c_dp, c_dp, c_dp, c_i64, c_dbl],
+    "nicp_rows": [c_dp, ctypes.POINTER(c_i64)],
     "nicp_deform": [c_dp, c_dp, c_dp, c_dp, c_dp],
     "nicp_residual": [c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_dp],
     "nicp_jvp": [c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_dp, c_dp],

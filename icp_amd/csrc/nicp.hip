@@ -41,6 +41,14 @@ struct nicp_graph {
     int32_t *rev_i = nullptr;      // [n*k] row vertex i of entry rev_ent[.]
     double *rev_w = nullptr;       // [n*k] its weight wt[rev_ent[.]]
     int32_t *inc_other = nullptr;  // [2e]  the edge's other endpoint
+    // optional row multipliers and landmark rows (nicp_set_weights / nicp_set_landmarks)
+    double *fw = nullptr, *gw = nullptr, *ew = nullptr;  // [n] fit, [n] rigidity, [e] smoothness
+    int64_t nl = 0;
+    int32_t *lm_v = nullptr;     // [nl] landmark vertex
+    double *lm_pos = nullptr;    // [nl,dim] landmark position
+    int32_t *lm_of = nullptr;    // [n] landmark row of a vertex, or -1
+    double c_land = 0.0;
+    double *f2 = nullptr;        // [n] fit_w^2 + (c_land/c_fit)^2 [landmark vertices]: fit block of J^T W^2 J
     // solver workspace (grow-once)
     double *ws = nullptr;
     size_t ws_doubles = 0;
@@ -78,12 +86,24 @@ struct Strides {
     int64_t fj, fo;  // fit rows        (dim per vertex)
     int64_t rj, rm;  // rigidity rows   (NRIG per vertex), relative to the start of the rigid block
     int64_t sj, so;  // smoothness rows (2*dim per edge), relative to the start of the smooth block
+    int64_t lj, lo;  // landmark rows   (dim per landmark), relative to the start of the landmark block
+};
+// Optional per-row multipliers and landmark rows; every pointer may be null (= the reference's energy).
+struct RowW {
+    const double *fit = nullptr, *rig = nullptr, *edge = nullptr;  // linear multipliers [n], [n], [e]
+    const double *f2 = nullptr;      // [n] squared fit multiplier incl. the landmark rows (see nicp_graph::f2)
+    const int32_t *lm_of = nullptr;  // [n] landmark row of a vertex or -1
+    const double *lm_pos = nullptr;  // [nl,dim]
+    double c_land = 0.0;
+    int64_t nl = 0;
 };
 template <int DIM>
 static inline Strides strides_aos() {
-    return {Lay<DIM>::S, 1, DIM, 1, DIM, 1, Lay<DIM>::NRIG, 1, 2 * DIM, 1};
+    return {Lay<DIM>::S, 1, DIM, 1, DIM, 1, Lay<DIM>::NRIG, 1, 2 * DIM, 1, DIM, 1};
 }
-static inline Strides strides_soa(int64_t n, int64_t ne) { return {1, n, 1, n, 1, n, 1, n, 1, ne > 0 ? ne : 1}; }
+static inline Strides strides_soa(int64_t n, int64_t ne, int64_t nl) {
+    return {1, n, 1, n, 1, n, 1, n, 1, ne > 0 ? ne : 1, 1, nl > 0 ? nl : 1};
+}
 
 // ------------------------------------------------------------------ KNN + weights
 // Exact k-nearest by the key the reference sorts on, sqrt(d2) (nicp_3d.py:53-57), with
@@ -279,10 +299,21 @@ __global__ __launch_bounds__(NB) void residual_kernel(const double *__restrict__
                                                      const double *__restrict__ nn, const double *__restrict__ dd,
                                                      const int32_t *__restrict__ edges, int64_t n, int64_t ne,
                                                      double c_fit, double c_rigid, double c_smooth,
-                                                     double *__restrict__ r, Strides st) {
+                                                     double *__restrict__ r, Strides st, RowW rw) {
     constexpr int NRIG = Lay<DIM>::NRIG, NA = Lay<DIM>::NA;
     const int64_t t = (int64_t)blockIdx.x * NB + threadIdx.x;
-    double *r_rig = r + n * DIM, *r_sm = r + n * DIM + n * NRIG;
+    double *r_rig = r + n * DIM, *r_sm = r + n * DIM + n * NRIG, *r_land = r_sm + 2 * DIM * ne;
+    if (t < n) {
+        if (rw.fit) c_fit *= rw.fit[t];
+        if (rw.rig) c_rigid *= rw.rig[t];
+        const int32_t lk = rw.lm_of ? rw.lm_of[t] : -1;
+        if (lk >= 0)
+#pragma unroll
+            for (int c = 0; c < DIM; ++c)
+                r_land[lk * st.lj + c * st.lo] = rw.c_land * (rw.lm_pos[(int64_t)lk * DIM + c] - dd[t * st.vj + c * st.vc]);
+    } else if (t < n + ne && rw.edge) {
+        c_smooth *= rw.edge[t - n];
+    }
     auto rig = [&](int64_t flat) { return (flat / NRIG) * st.rj + (flat % NRIG) * st.rm; };  // flat = reference slot
     if (t < n) {
 #pragma unroll
@@ -331,11 +362,29 @@ __global__ __launch_bounds__(NB) void jp_kernel(const double *__restrict__ P, co
                                                const double *__restrict__ v, const double *__restrict__ rs,
                                                const int32_t *__restrict__ edges, int64_t n, int64_t ne,
                                                const Globals *__restrict__ g, double c_fit, double c_rigid,
-                                               double c_smooth, double *__restrict__ y, Strides st) {
+                                               double c_smooth, double *__restrict__ y, Strides st, RowW rw, int sq) {
+    // sq = 0: y = W J p (rows as nicp_residual, landmark rows included); sq = 1: y = W^2 J p with the
+    // landmark rows folded into the fit rows (rw.f2), which is what J^T needs next in the CG operator
     constexpr int S = Lay<DIM>::S, NRIG = Lay<DIM>::NRIG, NANG = Lay<DIM>::NANG, NA = Lay<DIM>::NA;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    double *y_rig = y + n * DIM, *y_sm = y + n * DIM + n * NRIG;
+    double *y_rig = y + n * DIM, *y_sm = y + n * DIM + n * NRIG, *y_land = y_sm + 2 * DIM * ne;
     const double *ptail = p + n * S;
+    double c_land_row = 0.0;
+    int32_t lk = -1;
+    if (t < n) {
+        if (sq) {
+            if (rw.f2) c_fit *= rw.f2[t];
+            if (rw.rig) c_rigid *= rw.rig[t] * rw.rig[t];
+        } else {
+            if (rw.fit) c_fit *= rw.fit[t];
+            if (rw.rig) c_rigid *= rw.rig[t];
+            lk = rw.lm_of ? rw.lm_of[t] : -1;
+            c_land_row = rw.c_land;
+        }
+    } else if (t < n + ne && rw.edge) {
+        const double e = rw.edge[t - n];
+        c_smooth *= sq ? e * e : e;
+    }
     if (t < n) {
         // fit rows: nicp_3d.py:286-306
         double vi[DIM], acc[DIM];
@@ -386,6 +435,7 @@ __global__ __launch_bounds__(NB) void jp_kernel(const double *__restrict__ P, co
                 a += ptail[an] * b;
             }
             y[t * st.fj + o * st.fo] = -c_fit * a;
+            if (lk >= 0) y_land[lk * st.lj + o * st.lo] = -c_land_row * a;
         }
         // rigid rows: nicp_3d.py:309-314 / nicp_row.py:193-204
         double A[NA], pa[NA];
@@ -461,7 +511,9 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
                                                 const Globals *__restrict__ g, double c_fit, double c_rigid,
                                                 double c_smooth, const double *__restrict__ lam_d2,
                                                 const double *__restrict__ p_in, double lam, double *__restrict__ out,
-                                                double *__restrict__ partial, int64_t nown, Strides st) {
+                                                double *__restrict__ partial, int64_t nown, Strides st, RowW rw) {
+    // the row multipliers are already in u (jp_kernel with sq = 1, weight_rows_kernel); only the
+    // column sums of squares (SQUARE) read them here
     constexpr int NRIG = Lay<DIM>::NRIG, NANG = Lay<DIM>::NANG, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const double *u_rig = u + n * DIM, *u_sm = u + n * DIM + n * NRIG;
@@ -504,7 +556,7 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
             for (int q = 0; q < RB; ++q)
 #pragma unroll
                 for (int o = 0; o < DIM; ++o) {
-                    uu[q][o] = SQUARE ? 0.0 : u[(int64_t)ii[q] * st.fj + o * st.fo];
+                    uu[q][o] = SQUARE ? (rw.f2 ? rw.f2[ii[q]] : 1.0) : u[(int64_t)ii[q] * st.fj + o * st.fo];
                     vv[q][o] = v[(int64_t)ii[q] * st.vj + o * st.vc];
                 }
         };
@@ -520,7 +572,7 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
                     double a = 0.0;
 #pragma unroll
                     for (int o = 0; o < DIM; ++o) a += SQUARE ? Rm[c][o] * Rm[c][o] : Rm[c][o] * uu[q][o];
-                    yv[c] = a;
+                    yv[c] = SQUARE ? a * uu[q][0] : a;
                 }
 #pragma unroll
                 for (int r = 0; r < DIM; ++r) {
@@ -548,7 +600,9 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
 #pragma unroll
                 for (int o = 0; o < DIM; ++o) vo[q][o] = v[(int64_t)oth[q] * st.vj + o * st.vc];
 #pragma unroll
-                for (int o = 0; o < 2 * DIM; ++o) us[q][o] = SQUARE ? 1.0 : u_sm[(int64_t)(ent[q] >> 1) * st.sj + o * st.so];
+                for (int o = 0; o < 2 * DIM; ++o)
+                    us[q][o] = SQUARE ? (rw.edge ? rw.edge[ent[q] >> 1] * rw.edge[ent[q] >> 1] : 1.0)
+                                      : u_sm[(int64_t)(ent[q] >> 1) * st.sj + o * st.so];
             }
         };
         auto edge_accumulate = [&](int32_t e0, const int32_t (&ent)[IB], const double (&us)[IB][2 * DIM], const double (&vo)[IB][DIM]) {
@@ -562,10 +616,10 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
 #pragma unroll
                     for (int r = 0; r < DIM; ++r) {
                         const double d = end == 0 ? vo[q][r] - vj[r] : vj[r] - vo[q][r];
-                        if (SQUARE) gA[r][c] += c_smooth * c_smooth * d * d;
+                        if (SQUARE) gA[r][c] += c_smooth * c_smooth * d * d * u0;
                         else gA[r][c] += end == 0 ? c_smooth * d * u0 : -c_smooth * d * u1;
                     }
-                    if (SQUARE) gb[c] += 2 * c_smooth * c_smooth;
+                    if (SQUARE) gb[c] += 2 * c_smooth * c_smooth * u0;
                     else gb[c] += end == 0 ? c_smooth * (u0 - u1) : c_smooth * (u1 - u0);
                 }
             }
@@ -580,7 +634,7 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
 #pragma unroll
         for (int e = 0; e < Lay<DIM>::NA; ++e) Aown[e] = P[j * st.pj + e * st.pe];
 #pragma unroll
-        for (int e = 0; e < NRIG; ++e) urown[e] = SQUARE ? 0.0 : u_rig[j * st.rj + e * st.rm];
+        for (int e = 0; e < NRIG; ++e) urown[e] = SQUARE ? (rw.rig ? rw.rig[j] * rw.rig[j] : 1.0) : u_rig[j * st.rj + e * st.rm];
         fit_gather(ii0, uu0, vv0);
         edge_gather(ent0, oth0, us0, vo0);
 
@@ -601,9 +655,9 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
                 for (int c = 0; c < 3; ++c) {
                     const double a0 = A[c], a1 = A[3 + c], a2 = A[6 + c];
                     if (SQUARE) {
-                        gA[0][c] += c_rigid * c_rigid * (a1 * a1 + a2 * a2 + 4 * a0 * a0);
-                        gA[1][c] += c_rigid * c_rigid * (a0 * a0 + a2 * a2 + 4 * a1 * a1);
-                        gA[2][c] += c_rigid * c_rigid * (a1 * a1 + a0 * a0 + 4 * a2 * a2);
+                        gA[0][c] += c_rigid * c_rigid * ur[0] * (a1 * a1 + a2 * a2 + 4 * a0 * a0);
+                        gA[1][c] += c_rigid * c_rigid * ur[0] * (a0 * a0 + a2 * a2 + 4 * a1 * a1);
+                        gA[2][c] += c_rigid * c_rigid * ur[0] * (a1 * a1 + a0 * a0 + 4 * a2 * a2);
                     } else {
                         gA[0][c] += c_rigid * (ur[0] * a1 + ur[2] * a2 - 2 * ur[3] * a0);
                         gA[1][c] += c_rigid * (ur[0] * a0 + ur[1] * a2 - 2 * ur[4] * a1);
@@ -615,8 +669,8 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
                 for (int c = 0; c < 2; ++c) {
                     const double a0 = A[c], a1 = A[2 + c];
                     if (SQUARE) {
-                        gA[0][c] += c_rigid * c_rigid * (a1 * a1 + 4 * a0 * a0);
-                        gA[1][c] += c_rigid * c_rigid * (a0 * a0 + 4 * a1 * a1);
+                        gA[0][c] += c_rigid * c_rigid * ur[0] * (a1 * a1 + 4 * a0 * a0);
+                        gA[1][c] += c_rigid * c_rigid * ur[0] * (a0 * a0 + 4 * a1 * a1);
                     } else {
                         gA[0][c] += c_rigid * (ur[0] * a1 - 2 * ur[1] * a0);
                         gA[1][c] += c_rigid * (ur[0] * a0 - 2 * ur[2] * a1);
@@ -661,10 +715,11 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
                 for (int c = 0; c < DIM; ++c) b += rs[j * st.vj + c * st.vc] * g->dR[an][c * DIM + o];
                 a += SQUARE ? (c_fit * b) * (c_fit * b) : -c_fit * b * u[j * st.fj + o * st.fo];
             }
-            gacc[an] = a;
+            gacc[an] = SQUARE && rw.f2 ? a * rw.f2[j] : a;
         }
 #pragma unroll
-        for (int o = 0; o < DIM; ++o) gacc[NANG + o] = SQUARE ? c_fit * c_fit : -c_fit * u[j * st.fj + o * st.fo];
+        for (int o = 0; o < DIM; ++o)
+            gacc[NANG + o] = SQUARE ? c_fit * c_fit * (rw.f2 ? rw.f2[j] : 1.0) : -c_fit * u[j * st.fj + o * st.fo];
     }
     // halo copies (j >= nown) belong to another rank's sums
     if (j >= nown) {
@@ -850,7 +905,8 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
                                                        int64_t n, const Globals *__restrict__ g, double c_fit, double c_rigid,
                                                        double c_smooth, const double *__restrict__ col2,
                                                        const double *__restrict__ d2, double lam,
-                                                       double *__restrict__ binv, Coarse *__restrict__ coarse, Strides st) {
+                                                       double *__restrict__ binv, Coarse *__restrict__ coarse, Strides st,
+                                                       RowW rw) {
     constexpr int S = Lay<DIM>::S, NA = Lay<DIM>::NA, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (j == 0)
@@ -878,7 +934,7 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
         double u[S];  // the row pattern up to the R factor: u[r*DIM+c] = w d[r], u[NA+c] = wb (for column c)
         double d[DIM];
         for (int a = 0; a < DIM; ++a) d[a] = v[i * st.vj + a * st.vc] - vj[a];
-        const double cf2 = c_fit * c_fit;
+        const double cf2 = c_fit * c_fit * (rw.f2 ? rw.f2[i] : 1.0);
         for (int r = 0; r < DIM; ++r)
             for (int c = 0; c < DIM; ++c) {
                 for (int r2 = 0; r2 < DIM; ++r2)
@@ -897,7 +953,7 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
     {
         double A[NA];
         for (int e = 0; e < NA; ++e) A[e] = P[j * st.pj + e * st.pe];
-        const double cr2 = c_rigid * c_rigid;
+        const double cr2 = c_rigid * c_rigid * (rw.rig ? rw.rig[j] * rw.rig[j] : 1.0);
         constexpr int NRIG = Lay<DIM>::NRIG;
         double G[NRIG][NA];
         for (int m = 0; m < NRIG; ++m)
@@ -927,7 +983,7 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
         const int64_t ed = ent >> 1;
         const double sgn = (ent & 1) ? -1.0 : 1.0;
         const int64_t p1 = edges[ed * 2], p2 = edges[ed * 2 + 1];
-        const double cs2 = c_smooth * c_smooth;
+        const double cs2 = c_smooth * c_smooth * (rw.edge ? rw.edge[ed] * rw.edge[ed] : 1.0);
         double d[DIM];
         for (int a = 0; a < DIM; ++a) d[a] = v[p2 * st.vj + a * st.vc] - v[p1 * st.vj + a * st.vc];
         for (int c = 0; c < DIM; ++c) {
@@ -1325,6 +1381,59 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(const Scal *__restrict_
     }
 }
 
+// out = W^T-side weighting of a row vector u (rows as nicp_residual): fit rows take their multiplier and
+// the landmark row of the same vertex (whose Jacobian row is c_land/c_fit times the fit row), so that
+// J^T out = (W J)^T u with the unweighted J^T kernel.  out has no landmark block.
+template <int DIM>
+__global__ __launch_bounds__(NB) void weight_rows_kernel(const double *__restrict__ u, int64_t n, int64_t ne, double ratio,
+                                                        double *__restrict__ out, Strides st, RowW rw) {
+    constexpr int NRIG = Lay<DIM>::NRIG;
+    const int64_t t = (int64_t)blockIdx.x * NB + threadIdx.x;
+    const int64_t o_rig = n * DIM, o_sm = n * DIM + n * NRIG, o_land = o_sm + 2 * DIM * ne;
+    if (t < n) {
+        const double f = rw.fit ? rw.fit[t] : 1.0, gq = rw.rig ? rw.rig[t] : 1.0;
+        const int32_t lk = rw.lm_of ? rw.lm_of[t] : -1;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            double val = f * u[t * st.fj + c * st.fo];
+            if (lk >= 0) val += ratio * u[o_land + lk * st.lj + c * st.lo];
+            out[t * st.fj + c * st.fo] = val;
+        }
+#pragma unroll
+        for (int m = 0; m < NRIG; ++m) out[o_rig + t * st.rj + m * st.rm] = gq * u[o_rig + t * st.rj + m * st.rm];
+    } else if (t < n + ne) {
+        const int64_t ed = t - n;
+        const double e = rw.edge ? rw.edge[ed] : 1.0;
+#pragma unroll
+        for (int o = 0; o < 2 * DIM; ++o) out[o_sm + ed * st.sj + o * st.so] = e * u[o_sm + ed * st.sj + o * st.so];
+    }
+}
+// f2[i] = fit_w[i]^2 + ratio2 on landmark vertices
+__global__ __launch_bounds__(NB) void f2_kernel(const double *__restrict__ fw, const int32_t *__restrict__ lm_of, double ratio2,
+                                               int64_t n, double *__restrict__ f2) {
+    const int64_t t = (int64_t)blockIdx.x * NB + threadIdx.x;
+    if (t < n) {
+        const double f = fw ? fw[t] : 1.0;
+        f2[t] = f * f + (lm_of && lm_of[t] >= 0 ? ratio2 : 0.0);
+    }
+}
+__global__ __launch_bounds__(NB) void fill_i32_kernel(int32_t *__restrict__ a, int32_t val, int64_t n) {
+    const int64_t t = (int64_t)blockIdx.x * NB + threadIdx.x;
+    if (t < n) a[t] = val;
+}
+// lm_of[vertex[k]] = k; err[0] counts out-of-range vertices, err[1] duplicates
+__global__ __launch_bounds__(NB) void landmark_map_kernel(const int32_t *__restrict__ vertex, int64_t nl, int64_t n,
+                                                         int32_t *__restrict__ lm_of, int32_t *__restrict__ err) {
+    const int64_t k = (int64_t)blockIdx.x * NB + threadIdx.x;
+    if (k >= nl) return;
+    const int32_t vtx = vertex[k];
+    if (vtx < 0 || vtx >= n) {
+        atomicAdd(&err[0], 1);
+        return;
+    }
+    if (atomicCAS(&lm_of[vtx], -1, (int32_t)k) != -1) atomicAdd(&err[1], 1);
+}
+
 static inline int vgrid(const nicp_graph *g, int64_t len) { return (int)((len + g->vb - 1) / g->vb); }
 static inline int grid_for(int64_t len, int cap = 1024) {
     int64_t nb = (len + NB - 1) / NB;
@@ -1345,7 +1454,7 @@ static Dims dims_of(const nicp_graph *g) {
     d.n = g->n;
     d.e = g->e;
     d.np = g->n * d.S + d.NG;
-    d.nr = g->n * g->dim + g->n * d.NRIG + 2 * g->dim * g->e;
+    d.nr = g->n * g->dim + g->n * d.NRIG + 2 * g->dim * g->e + g->dim * g->nl;
     return d;
 }
 
@@ -1363,6 +1472,8 @@ struct Work {
     double *tot;                           // 64 reduced sums (the all-reduce buffer when no comm is given)
     double *xs, *vs, *nns, *masks;         // solver-internal (lane-transposed) copies of P, v, nn and the row mask
     Strides st;                            // layout the helpers below index with (reference layout by default)
+    RowW rw;                               // row multipliers / landmark rows of the graph (all null: none)
+    bool weighted = false;
 };
 
 static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
@@ -1407,6 +1518,16 @@ static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     w.nns = p; p += (size_t)d.n * d.dim;
     w.masks = p;
     w.st = d.dim == 3 ? strides_aos<3>() : strides_aos<2>();
+    w.rw = RowW();
+    w.rw.fit = g->fw;
+    w.rw.rig = g->gw;
+    w.rw.edge = g->ew;
+    w.rw.f2 = (g->fw || g->nl) ? g->f2 : nullptr;
+    w.rw.lm_of = g->nl ? g->lm_of : nullptr;
+    w.rw.lm_pos = g->lm_pos;
+    w.rw.c_land = g->c_land;
+    w.rw.nl = g->nl;
+    w.weighted = g->fw || g->gw || g->ew || g->nl;
     return ICP_OK;
 }
 
@@ -1441,19 +1562,51 @@ static int residual_at(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, co
     const int nbk = grid_for(g->n + g->e, 1 << 30);
     NICP_DISPATCH(g->dim, compat,
                   hipLaunchKernelGGL((residual_kernel<D, C>), dim3(nbk), dim3(NB), 0, ctx->stream, P, v, nn, w.dd, g->edges,
-                                     g->n, g->e, c[0], c[1], c[2], r_out, w.st));
+                                     g->n, g->e, c[0], c[1], c[2], r_out, w.st, w.rw));
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
 }
 
-// y = J p at the linearisation held in w (call linearise first)
+static int refuse_compat_weights(const Work &w, bool compat) {
+    if (compat && w.weighted) {
+        set_error("nicp: NICP_REFERENCE_COMPAT has no meaning on a graph with row weights or landmarks");
+        return ICP_ERR_UNSUPPORTED;
+    }
+    return ICP_OK;
+}
+
+// (c_land / c_fit)^2 folded into the fit rows: refresh g->f2 for this call's c_fit
+static int prepare_weights(icp_ctx *ctx, nicp_graph *g, Work &w, const double *c) {
+    if (!w.rw.f2) return ICP_OK;
+    if (g->nl && !(c[0] > 0.0)) {
+        set_error("nicp: landmark rows need c_fit > 0 (they ride on the fit rows as c_land/c_fit)");
+        return ICP_ERR_ARG;
+    }
+    const double ratio = g->nl ? g->c_land / c[0] : 0.0;
+    hipLaunchKernelGGL(f2_kernel, dim3(grid_for(g->n, 1 << 30)), dim3(NB), 0, ctx->stream, (const double *)g->fw, w.rw.lm_of, ratio * ratio,
+                       g->n, g->f2);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+// out = W-weighted copy of the row vector u for the J^T kernel (see weight_rows_kernel); only on weighted graphs
+static int weight_rows(icp_ctx *ctx, nicp_graph *g, Work &w, const double *c, const double *u, double *out) {
+    const double ratio = g->nl ? g->c_land / c[0] : 0.0;
+    const int nbk = grid_for(g->n + g->e, 1 << 30);
+    if (g->dim == 3) hipLaunchKernelGGL(weight_rows_kernel<3>, dim3(nbk), dim3(NB), 0, ctx->stream, u, g->n, g->e, ratio, out, w.st, w.rw);
+    else hipLaunchKernelGGL(weight_rows_kernel<2>, dim3(nbk), dim3(NB), 0, ctx->stream, u, g->n, g->e, ratio, out, w.st, w.rw);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+// y = W J p (sq = 0) or W^2 J p (sq = 1) at the linearisation held in w (call linearise first)
 static int apply_J(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, const double *v, const double *c, bool compat,
-                   const double *p, double *y) {
+                   const double *p, double *y, int sq) {
     const int nbk = vgrid(g, g->n + g->e);
     const double *rs = compat ? w.dd : w.pre;  // Q6
     NICP_DISPATCH(g->dim, compat,
                   hipLaunchKernelGGL((jp_kernel<D, C>), dim3(nbk), dim3(g->vb), 0, ctx->stream, P, p, g->nbr, g->wt, g->k, v, rs,
-                                     g->edges, g->n, g->e, w.glob, c[0], c[1], c[2], y, w.st));
+                                     g->edges, g->n, g->e, w.glob, c[0], c[1], c[2], y, w.st, w.rw, sq));
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
 }
@@ -1524,12 +1677,12 @@ static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const 
         NICP_DISPATCH(g->dim, compat,
                       hipLaunchKernelGGL((jtu_kernel<D, C, true>), dim3(nbk), dim3(g->vb), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,
                                          rs, g->edges, g->rev_ptr, g->rev_i, g->rev_w, g->inc_ptr, g->inc_ent, g->inc_other, g->n, g->e, w.glob,
-                                         c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial, par.nown, w.st));
+                                         c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial, par.nown, w.st, w.rw));
     } else {
         NICP_DISPATCH(g->dim, compat,
                       hipLaunchKernelGGL((jtu_kernel<D, C, false>), dim3(nbk), dim3(g->vb), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,
                                          rs, g->edges, g->rev_ptr, g->rev_i, g->rev_w, g->inc_ptr, g->inc_ent, g->inc_other, g->n, g->e, w.glob,
-                                         c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial, par.nown, w.st));
+                                         c[0], c[1], c[2], lam_d2, p_in, lam, out, w.partial, par.nown, w.st, w.rw));
     }
     ICP_HIP_CHECK(hipGetLastError());
     if (!finish_tail) return ICP_OK;
@@ -1663,7 +1816,8 @@ extern "C" int nicp_graph_destroy(icp_ctx *ctx, nicp_graph *g) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    void *ptrs[] = {g->nbr, g->wt, g->edges, g->rev_ptr, g->rev_ent, g->inc_ptr, g->inc_ent, g->rev_i, g->rev_w, g->inc_other, g->ws};
+    void *ptrs[] = {g->nbr, g->wt, g->edges, g->rev_ptr, g->rev_ent, g->inc_ptr, g->inc_ent, g->rev_i, g->rev_w, g->inc_other, g->ws,
+                    g->fw, g->gw, g->ew, g->lm_v, g->lm_pos, g->lm_of, g->f2};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -1740,6 +1894,92 @@ extern "C" int nicp_graph_create(icp_ctx *ctx, const int32_t *nbr_dev, const dou
     return ICP_OK;
 }
 
+// ---- extended energy: row multipliers and landmark rows (no counterpart in the reference)
+static int replace_copy(icp_ctx *ctx, double **slot, const double *src_dev, int64_t count) {
+    if (*slot) {
+        ICP_HIP_CHECK(hipFree(*slot));
+        *slot = nullptr;
+    }
+    if (!src_dev || count <= 0) return ICP_OK;
+    if (hipMalloc((void **)slot, count * sizeof(double)) != hipSuccess) {
+        set_error("nicp weights: hipMalloc(%lld doubles) failed", (long long)count);
+        return ICP_ERR_NOMEM;
+    }
+    ICP_HIP_CHECK(hipMemcpyAsync(*slot, src_dev, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return ICP_OK;
+}
+static int ensure_f2(nicp_graph *g) {
+    if (g->f2) return ICP_OK;
+    if (hipMalloc((void **)&g->f2, g->n * sizeof(double)) != hipSuccess) {
+        set_error("nicp weights: hipMalloc failed");
+        return ICP_ERR_NOMEM;
+    }
+    return ICP_OK;
+}
+
+extern "C" int nicp_set_weights(icp_ctx *ctx, nicp_graph *g, const double *fit_w_dev, const double *rigid_w_dev,
+                                const double *edge_w_dev) {
+    ICP_REQUIRE(ctx && g, "null handle");
+    ICP_HIP_CHECK(hipSetDevice(ctx->device));
+    ICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // earlier work may still read the old arrays
+    if (int rc = replace_copy(ctx, &g->fw, fit_w_dev, g->n)) return rc;
+    if (int rc = replace_copy(ctx, &g->gw, rigid_w_dev, g->n)) return rc;
+    if (int rc = replace_copy(ctx, &g->ew, edge_w_dev, g->e)) return rc;
+    if (g->fw)
+        if (int rc = ensure_f2(g)) return rc;
+    ICP_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the caller may free its arrays on return
+    return ICP_OK;
+}
+
+extern "C" int nicp_set_landmarks(icp_ctx *ctx, nicp_graph *g, const int32_t *vertex_dev, const double *pos_dev, int64_t nl,
+                                  double c_land) {
+    ICP_REQUIRE(ctx && g, "null handle");
+    ICP_REQUIRE(nl >= 0 && nl <= g->n && (nl == 0 || (vertex_dev && pos_dev)), "bad landmark arguments");
+    ICP_REQUIRE(nl == 0 || (c_land >= 0.0 && c_land == c_land), "c_land must be a non-negative number");
+    ICP_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    ICP_HIP_CHECK(hipStreamSynchronize(st));
+    if (g->lm_v) ICP_HIP_CHECK(hipFree(g->lm_v));
+    g->lm_v = nullptr;
+    if (int rc = replace_copy(ctx, &g->lm_pos, nullptr, 0)) return rc;
+    g->nl = 0;
+    g->c_land = 0.0;
+    if (nl == 0) return ICP_OK;
+    if (!g->lm_of && hipMalloc((void **)&g->lm_of, (g->n + 2) * sizeof(int32_t)) != hipSuccess) {
+        set_error("nicp landmarks: hipMalloc failed");
+        return ICP_ERR_NOMEM;
+    }
+    if (int rc = ensure_f2(g)) return rc;
+    if (hipMalloc((void **)&g->lm_v, nl * sizeof(int32_t)) != hipSuccess) {
+        set_error("nicp landmarks: hipMalloc failed");
+        return ICP_ERR_NOMEM;
+    }
+    ICP_HIP_CHECK(hipMemcpyAsync(g->lm_v, vertex_dev, nl * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (int rc = replace_copy(ctx, &g->lm_pos, pos_dev, nl * g->dim)) return rc;
+    // lm_of[n], then two error counters behind it
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(g->n, 1 << 30)), dim3(NB), 0, st, g->lm_of, -1, g->n);
+    ICP_HIP_CHECK(hipMemsetAsync(g->lm_of + g->n, 0, 2 * sizeof(int32_t), st));
+    hipLaunchKernelGGL(landmark_map_kernel, dim3(grid_for(nl, 1 << 30)), dim3(NB), 0, st, (const int32_t *)g->lm_v, nl, g->n, g->lm_of,
+                       g->lm_of + g->n);
+    ICP_HIP_CHECK(hipGetLastError());
+    int32_t bad[2] = {0, 0};
+    ICP_HIP_CHECK(hipMemcpyAsync(bad, g->lm_of + g->n, sizeof(bad), hipMemcpyDeviceToHost, st));
+    ICP_HIP_CHECK(hipStreamSynchronize(st));
+    if (bad[0] || bad[1]) {
+        set_error("nicp_set_landmarks: %d vertex ids out of range, %d repeated", bad[0], bad[1]);
+        return ICP_ERR_ARG;  // g->nl stays 0: the graph is left without landmarks
+    }
+    g->nl = nl;
+    g->c_land = c_land;
+    return ICP_OK;
+}
+
+extern "C" int nicp_rows(const nicp_graph *g, int64_t *rows_out) {
+    ICP_REQUIRE(g && rows_out, "null pointer");
+    *rows_out = dims_of(g).nr;
+    return ICP_OK;
+}
+
 #define NICP_ARGS(ctx, g)                                     \
     ICP_REQUIRE(ctx != nullptr && g != nullptr, "null handle"); \
     ICP_HIP_CHECK(hipSetDevice(ctx->device));                 \
@@ -1758,6 +1998,7 @@ extern "C" int nicp_residual(icp_ctx *ctx, nicp_graph *g, const double *P, const
                              const double *c3_host, unsigned flags, double *r_out) {
     NICP_ARGS(ctx, g);
     ICP_REQUIRE(P && v && nn && c3_host && r_out, "null pointer");
+    if (int rc = refuse_compat_weights(w, flags & 1u)) return rc;
     return residual_at(ctx, g, w, P, v, nn, c3_host, flags & 1u, r_out);
 }
 
@@ -1765,15 +2006,22 @@ extern "C" int nicp_jvp(icp_ctx *ctx, nicp_graph *g, const double *P, const doub
                         unsigned flags, const double *p_in, double *y_out) {
     NICP_ARGS(ctx, g);
     ICP_REQUIRE(P && v && c3_host && p_in && y_out, "null pointer");
+    if (int rc = refuse_compat_weights(w, flags & 1u)) return rc;
     if (int rc = linearise(ctx, g, w, P, v)) return rc;
-    return apply_J(ctx, g, w, P, v, c3_host, flags & 1u, p_in, y_out);
+    return apply_J(ctx, g, w, P, v, c3_host, flags & 1u, p_in, y_out, 0);
 }
 
 extern "C" int nicp_jtvp(icp_ctx *ctx, nicp_graph *g, const double *P, const double *v, const double *c3_host,
                          unsigned flags, const double *u_in, double *g_out) {
     NICP_ARGS(ctx, g);
     ICP_REQUIRE(P && v && c3_host && u_in && g_out, "null pointer");
+    if (int rc = refuse_compat_weights(w, flags & 1u)) return rc;
     if (int rc = linearise(ctx, g, w, P, v)) return rc;
+    if (w.weighted) {
+        if (g->nl) ICP_REQUIRE(c3_host[0] > 0.0, "landmark rows need c_fit > 0");
+        if (int rc = weight_rows(ctx, g, w, c3_host, u_in, w.y)) return rc;
+        u_in = w.y;
+    }
     return apply_JT(ctx, g, w, par_single(g, w), P, v, c3_host, flags & 1u, u_in, nullptr, nullptr, 0.0, g_out, false);
 }
 
@@ -1806,7 +2054,9 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
     const int64_t nown = par_in.nown;
 
     // ---- solver-internal, lane-transposed copies of the inputs (see Strides)
-    const Strides ext = w.st, soa = strides_soa(d.n, d.e);
+    if (int rc = refuse_compat_weights(w, compat)) return rc;
+    if (int rc = prepare_weights(ctx, g, w, c)) return rc;
+    const Strides ext = w.st, soa = strides_soa(d.n, d.e, g->nl);
     Par par = par_in;
     if (int rc = relayout(ctx, P_inout, ext.pj, ext.pe, w.xs, soa.pj, soa.pe, d.n, d.S)) return rc;
     ICP_HIP_CHECK(hipMemcpyAsync(w.xs + d.n * d.S, P_inout + d.n * d.S, d.NG * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -1817,6 +2067,8 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
         if (int rc = relayout(ctx, par.row_mask, ext.fj, ext.fo, w.masks, soa.fj, soa.fo, d.n, d.dim)) return rc;
         if (int rc = relayout(ctx, par.row_mask + o_rig, ext.rj, ext.rm, w.masks + o_rig, soa.rj, soa.rm, d.n, d.NRIG)) return rc;
         if (int rc = relayout(ctx, par.row_mask + o_sm, ext.sj, ext.so, w.masks + o_sm, soa.sj, soa.so, d.e, 2 * d.dim)) return rc;
+        const int64_t o_land = o_sm + 2 * d.dim * d.e;
+        if (int rc = relayout(ctx, par.row_mask + o_land, ext.lj, ext.lo, w.masks + o_land, soa.lj, soa.lo, g->nl, d.dim)) return rc;
         par.row_mask = w.masks;
     }
     w.st = soa;
@@ -1840,7 +2092,12 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
         }
         // linearise at x (w.r holds r(x) and w.pre/dd/glob are those of x after residual_at)
         if (int rc = linearise(ctx, g, w, x, v)) return rc;
-        if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.r, nullptr, nullptr, 0.0, w.grad, false)) return rc;
+        const double *r_for_grad = w.r;  // gradient (W J)^T r = J^T (W r [+ landmark rows on their fit rows])
+        if (w.weighted) {
+            if (int rc = weight_rows(ctx, g, w, c, w.r, w.y)) return rc;
+            r_for_grad = w.y;
+        }
+        if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, r_for_grad, nullptr, nullptr, 0.0, w.grad, false)) return rc;
         if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.r, nullptr, nullptr, 0.0, w.col2, true)) return rc;
         bool accepted = false;
         bool relinearise = false;
@@ -1861,12 +2118,12 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                                              (const double *)g->wt, g->k, v, (const int32_t *)g->edges, (const int32_t *)g->rev_ptr,
                                              (const int32_t *)g->rev_ent, (const int32_t *)g->inc_ptr, (const int32_t *)g->inc_ent, d.n,
                                              (const Globals *)w.glob, c[0], c[1], c[2], (const double *)w.col2, (const double *)w.d2, lam,
-                                             w.binv, w.coarse, w.st));
+                                             w.binv, w.coarse, w.st, w.rw));
             ICP_HIP_CHECK(hipGetLastError());
             for (int a = 0; a < nz; ++a) {  // E[:, a] = Z^T (J^T J + lam D^2) z_a
                 if (g->dim == 3) hipLaunchKernelGGL(zcol_kernel<3>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z, w.st);
                 else hipLaunchKernelGGL(zcol_kernel<2>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z, w.st);
-                if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.z, w.y)) return rc;
+                if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.z, w.y, 1)) return rc;
                 if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.y, w.d2, w.z, lam, w.Ap, false, false)) return rc;
                 hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask, par.tot, 8);
                 if (g->dim == 3) hipLaunchKernelGGL(zt_kernel<3>, dim3(nbv), dim3(g->vb), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial, w.st);
@@ -1912,7 +2169,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             for (int ci = 0; ci < o.max_cg_iters && !cg_done;) {
                 const int chunk = std::min(50, o.max_cg_iters - ci);
                 for (int k = 0; k < chunk; ++k) {
-                    if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.pcg, w.y)) return rc;
+                    if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.pcg, w.y, 1)) return rc;
                     if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.y, w.d2, w.pcg, lam, w.Ap, false, false)) return rc;
                     if (!par.sharded()) {
                         hipLaunchKernelGGL(cg_sum_alpha_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask | (1u << 8),

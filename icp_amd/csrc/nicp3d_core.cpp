@@ -198,6 +198,30 @@ int nicp3d::runNICP(const Array2D<double> &ptsSrc, const Array2D<int> &edgSrc, c
     check(icp_memcpy_h2d(ctx_, dp.p, params.data(), sizeof(double) * params.dim1()), "h2d");
     releaseGraph();
     check(nicp_graph_create(ctx_, dn.as<int32_t>(), dw.as<double>(), n, NUM_NN, de.as<int32_t>(), e, 3, &graph_), "nicp_graph_create");
+    {   // extended energy, when the caller filled it in
+        auto sized = [](const std::vector<double> &a, int want, const char *what) {
+            if (!a.empty() && (int)a.size() != want) throw std::runtime_error(std::string(what) + ": wrong length");
+        };
+        sized(fitWeight, n, "fitWeight");
+        sized(rigidWeight, n, "rigidWeight");
+        sized(edgeStiffness, e, "edgeStiffness");
+        DevBuf df(ctx_, sizeof(double) * (n ? n : 1)), dg(ctx_, sizeof(double) * (n ? n : 1)), ds(ctx_, sizeof(double) * (e ? e : 1));
+        if (!fitWeight.empty()) check(icp_memcpy_h2d(ctx_, df.p, fitWeight.data(), sizeof(double) * n), "h2d");
+        if (!rigidWeight.empty()) check(icp_memcpy_h2d(ctx_, dg.p, rigidWeight.data(), sizeof(double) * n), "h2d");
+        if (!edgeStiffness.empty()) check(icp_memcpy_h2d(ctx_, ds.p, edgeStiffness.data(), sizeof(double) * e), "h2d");
+        if (!fitWeight.empty() || !rigidWeight.empty() || !edgeStiffness.empty())
+            check(nicp_set_weights(ctx_, graph_, fitWeight.empty() ? nullptr : df.as<double>(),
+                                   rigidWeight.empty() ? nullptr : dg.as<double>(), edgeStiffness.empty() ? nullptr : ds.as<double>()),
+                  "nicp_set_weights");
+        const int nl = (int)landmarkVertex.size();
+        if (nl) {
+            if (landmarkPos.dim1() != nl || landmarkPos.dim2() != 3) throw std::runtime_error("landmarkPos: must be [landmarks,3]");
+            DevBuf dl(ctx_, sizeof(int32_t) * nl), dq(ctx_, sizeof(double) * nl * 3);
+            check(icp_memcpy_h2d(ctx_, dl.p, landmarkVertex.data(), sizeof(int32_t) * nl), "h2d");
+            check(icp_memcpy_h2d(ctx_, dq.p, landmarkPos.data(), sizeof(double) * nl * 3), "h2d");
+            check(nicp_set_landmarks(ctx_, graph_, dl.as<int32_t>(), dq.as<double>(), nl, cLand), "nicp_set_landmarks");
+        }
+    }
     std::vector<double> hist(run > 0 ? run : 1);
     int iters = 0;
     check(nicp_run(ctx_, graph_, dp.as<double>(), dv.as<double>(), dt.as<double>(), m, tol, run, c,

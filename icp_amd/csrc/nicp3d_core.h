@@ -85,6 +85,13 @@ public:
     Array2D<int> nbr;
     Array2D<double> wt;
     double c[3] = {INIT_C_FIT, INIT_C_RIGID, INIT_C_SMOOTH};
+    // Extended energy for runNICP (include/icp_hip.h nicp_set_weights / nicp_set_landmarks; not in the
+    // reference): empty = absent.  fitWeight / rigidWeight per vertex, edgeStiffness per edge,
+    // landmarkVertex[k] pulled towards landmarkPos[k] with cLand.  Needs reference_compat = false.
+    std::vector<double> fitWeight, rigidWeight, edgeStiffness;
+    std::vector<int> landmarkVertex;
+    Array2D<double> landmarkPos;
+    double cLand = 0.0;
     std::string lastError() const;
 
 private:

@@ -81,6 +81,46 @@ class SparseWeights:
             self._graphs[key] = (h, ne)
         return self._graphs[key]
 
+    # -- extended energy (not in the reference) -----------
+    def set_weights(self, edges, fit_w=None, rigid_w=None, edge_w=None):
+        """Per-vertex multipliers of c_fit / c_rigid and per-edge multipliers of c_smooth ("per-edge
+        stiffness") on the graph of these weights + `edges`; None = 1 everywhere."""
+        ctx = self.ctx
+        g, ne = self.graph(edges)
+        n = self.shape[0]
+        arrs = []
+        for a, cnt in ((fit_w, n), (rigid_w, n), (edge_w, ne)):
+            if a is None:
+                arrs.append(None)
+                continue
+            t = ctx.to_dev(a)
+            if tuple(t.shape) != (cnt,):
+                raise ValueError("weight array of shape %s, expected (%d,)" % (tuple(t.shape), cnt))
+            if bool((t < 0).any()) or not bool(ctx.torch.isfinite(t).all()):
+                raise ValueError("row multipliers must be finite and non-negative")
+            arrs.append(t)
+        ctx.call("nicp_set_weights", g, ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]))
+
+    def set_landmarks(self, edges, vertex=None, pos=None, c_land=0.0):
+        """Landmark rows c_land * (pos[k] - Deform(P)[vertex[k]]) appended to the residual; vertex=None removes them."""
+        ctx = self.ctx
+        g, _ = self.graph(edges)
+        if vertex is None or len(vertex) == 0:
+            ctx.call("nicp_set_landmarks", g, None, None, 0, 0.0)
+            return
+        vt = ctx.to_dev(vertex, ctx.torch.int32)
+        ps = ctx.to_dev(pos)
+        if tuple(ps.shape) != (vt.shape[0], self.dim):
+            raise ValueError("landmark positions must be [%d,%d]" % (vt.shape[0], self.dim))
+        ctx.call("nicp_set_landmarks", g, ptr(vt), ptr(ps), vt.shape[0], float(c_land))
+
+    def rows(self, edges):
+        """length of the residual vector of the graph (landmark rows included)"""
+        g, _ = self.graph(edges)
+        out = ctypes.c_int64()
+        _lib.check(self.ctx.lib.nicp_rows(g, ctypes.byref(out)))
+        return out.value
+
     def __del__(self):
         try:
             for h, _ in self._graphs.values():
@@ -153,7 +193,7 @@ def residual(P, w, source, edges, nn, c, compat=True, ctx=None):
     w = _as_weights(w, v.shape[1], ctx)
     g, ne = w.graph(edges)
     Pd, nnd = ctx.to_dev(P), ctx.to_dev(nn)
-    r = ctx.empty((n_rows(v.shape[0], ne, v.shape[1]),))
+    r = ctx.empty((w.rows(edges),))
     ctx.call("nicp_residual", g, ptr(Pd), ptr(v), ptr(nnd), _c3(c), 1 if compat else 0, ptr(r))
     return r
 
@@ -164,7 +204,7 @@ def jvp(P, w, source, edges, c, p, compat=True, ctx=None):
     w = _as_weights(w, v.shape[1], ctx)
     g, ne = w.graph(edges)
     Pd, pd = ctx.to_dev(P), ctx.to_dev(p)
-    y = ctx.empty((n_rows(v.shape[0], ne, v.shape[1]),))
+    y = ctx.empty((w.rows(edges),))
     ctx.call("nicp_jvp", g, ptr(Pd), ptr(v), _c3(c), 1 if compat else 0, ptr(pd), ptr(y))
     return y
 

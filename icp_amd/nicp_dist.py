@@ -112,6 +112,22 @@ class Shard:
         """Rows of a per-vertex global array [n, width] (or flat) in local order."""
         return np.ascontiguousarray(np.asarray(arr).reshape(-1, width)[self.local_ids])
 
+    def local_weights(self, fit_w=None, rigid_w=None, edge_w=None):
+        """Global row multipliers (nicp_set_weights) cut to this rank's local vertices / edges."""
+        cut = lambda a, ids: None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float64)[ids])
+        return cut(fit_w, self.local_ids), cut(rigid_w, self.local_ids), cut(edge_w, self.edge_ids)
+
+    def local_landmarks(self, vertex):
+        """Landmarks this rank evaluates: those on a local vertex whose fit row it holds (set F).
+        Returns (positions in the global landmark list, local vertex ids, row mask with the landmark
+        rows appended: a landmark row belongs to the owner of its vertex)."""
+        vertex = np.asarray(vertex).astype(np.int64).reshape(-1)
+        loc = self.g2l[vertex]
+        sel = np.nonzero((loc >= 0) & self.fit_rows[np.maximum(loc, 0)])[0]
+        lv = loc[sel]
+        mask = np.concatenate([self.row_mask, np.repeat((lv < self.n_owned).astype(np.float64), self.dim)])
+        return sel, lv.astype(np.int32), mask
+
     def local_params(self, P):
         """Local parameter vector [owned | halo | tail] from the global one."""
         S = self.dim * self.dim + self.dim
@@ -274,6 +290,23 @@ class ShardedNICP:
             P0 = _nicp.initial_params(self.n_global, self.dim)
         self.P = ctx.to_dev(sh.local_params(P0))
         self._torch = torch
+
+    # extended energy (include/icp_hip.h nicp_set_weights / nicp_set_landmarks), global arrays in
+    def set_weights(self, fit_w=None, rigid_w=None, edge_w=None):
+        f, g, e = self.shard.local_weights(fit_w, rigid_w, edge_w)
+        self.weights.set_weights(self.shard.edges if len(self.shard.edges) else None, f, g, e)
+
+    def set_landmarks(self, vertex=None, pos=None, c_land=0.0):
+        sh, comm = self.shard, self.comm
+        edges = sh.edges if len(sh.edges) else None
+        if vertex is None or len(vertex) == 0:
+            self.weights.set_landmarks(edges)
+            mask = sh.row_mask
+        else:
+            sel, lv, mask = sh.local_landmarks(vertex)
+            self.weights.set_landmarks(edges, lv, np.asarray(pos, dtype=np.float64).reshape(-1, self.dim)[sel], c_land)
+        comm.row_mask = self._torch.from_numpy(np.ascontiguousarray(mask)).to(comm.reduce_buf.device)
+        comm.struct.row_mask_dev = ctypes.c_void_p(comm.row_mask.data_ptr())
 
     def deform(self):
         out = self.ctx.empty(tuple(self.v.shape))

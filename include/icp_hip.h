@@ -182,6 +182,24 @@ int nicp_graph_create(icp_ctx *ctx, const int32_t *nbr_dev, const double *wt_dev
                       const int32_t *edges_dev, int64_t e, int dim, nicp_graph **out);
 int nicp_graph_destroy(icp_ctx *ctx, nicp_graph *g);
 
+/* Extended energy.  No counterpart in the reference, whose three
+ * stiffness constants are module globals (nicp_3d.py:17-20) applied uniformly: these attach
+ * per-row multipliers and landmark rows to a graph, and every operator below (nicp_residual,
+ * nicp_jvp, nicp_jtvp, nicp_solve, nicp_solve_dist, nicp_run) then works on
+ *   [c_fit fit_w_i (nn_i - Deform_i) | c_rigid rigid_w_i e_rigid_i | c_smooth edge_w_e e_smooth_e |
+ *    c_land (L_k - Deform_{l_k})].
+ * nicp_set_weights: fit_w_dev[n], rigid_w_dev[n], edge_w_dev[e] are DEVICE arrays of non-negative
+ * multipliers, copied; any of them may be NULL (= 1 everywhere); all NULL removes the weights.
+ * nicp_set_landmarks: nl landmark rows, vertex_dev[nl] (distinct vertex ids) pulled towards
+ * pos_dev[nl,dim] with the constant c_land; the rows are appended after the smoothness rows, dim per
+ * landmark, in the order given; nl = 0 removes them.  nicp_rows returns the length of the residual
+ * vector of the graph as it is now.  Weighted graphs refuse NICP_REFERENCE_COMPAT. */
+int nicp_set_weights(icp_ctx *ctx, nicp_graph *g, const double *fit_w_dev, const double *rigid_w_dev,
+                     const double *edge_w_dev);
+int nicp_set_landmarks(icp_ctx *ctx, nicp_graph *g, const int32_t *vertex_dev, const double *pos_dev,
+                       int64_t nl, double c_land);
+int nicp_rows(const nicp_graph *g, int64_t *rows_out);
+
 /* Deform: nicp_3d.py:220-233 / nicp_row.py:112-126 / nicp3d.cpp:277-371.  P has
  * (dim*dim+dim)*n + (dim==3 ? 6 : 3) entries (PtoAB layout, nicp_3d.py:171-175). */
 int nicp_deform(icp_ctx *ctx, nicp_graph *g, const double *P, const double *v, double *out);

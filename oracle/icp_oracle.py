@@ -487,6 +487,45 @@ def d_min_func(P, nbr, wt, srcdata, edges, tgtdata, c=(C_FIT, C_RIGID, C_SMOOTH)
     return np.concatenate([J_fit * c[0], J_rig * c[1], J_sm * c[2]], axis=0)
 
 
+def row_multipliers(n, ne, dim, fit_w=None, rigid_w=None, edge_w=None):
+    """Per-row multipliers of the extended energy (include/icp_hip.h nicp_set_weights; no
+    counterpart in the reference), in the row order of min_func(compat=False)."""
+    nrig = 6 if dim == 3 else 3
+    f = np.ones(n) if fit_w is None else np.asarray(fit_w, dtype=np.float64)
+    g = np.ones(n) if rigid_w is None else np.asarray(rigid_w, dtype=np.float64)
+    e = np.ones(ne) if edge_w is None else np.asarray(edge_w, dtype=np.float64)
+    return np.concatenate([np.repeat(f, dim), np.repeat(g, nrig), np.repeat(e, 2 * dim)])
+
+
+def min_func_ext(P, nbr, wt, srcdata, edges, tgtdata, c, fit_w=None, rigid_w=None, edge_w=None,
+                 lm_vertex=None, lm_pos=None, c_land=0.0):
+    """min_func(compat=False) with row multipliers, followed by the landmark rows
+    c_land * (L_k - Deform(P)[l_k]) (nicp_set_landmarks)."""
+    srcdata = np.asarray(srcdata, dtype=np.float64)
+    n, dim = srcdata.shape
+    r = min_func(P, nbr, wt, srcdata, edges, tgtdata, c, compat=False)
+    r = r * row_multipliers(n, edges.shape[0], dim, fit_w, rigid_w, edge_w)
+    if lm_vertex is not None and len(lm_vertex):
+        dd = deform(P, nbr, wt, srcdata)
+        r = np.concatenate([r, (c_land * (np.asarray(lm_pos) - dd[np.asarray(lm_vertex)])).flatten()])
+    return r
+
+
+def d_min_func_ext(P, nbr, wt, srcdata, edges, tgtdata, c, fit_w=None, rigid_w=None, edge_w=None,
+                   lm_vertex=None, lm_pos=None, c_land=0.0):
+    """Jacobian of min_func_ext: weighted rows of d_min_func(compat=False); a landmark row is the fit
+    row of its vertex with c_land in place of c_fit."""
+    srcdata = np.asarray(srcdata, dtype=np.float64)
+    n, dim = srcdata.shape
+    J = d_min_func(P, nbr, wt, srcdata, edges, tgtdata, c, compat=False)
+    Jw = J * row_multipliers(n, edges.shape[0], dim, fit_w, rigid_w, edge_w)[:, None]
+    if lm_vertex is not None and len(lm_vertex):
+        J1 = d_min_func(P, nbr, wt, srcdata, edges, tgtdata, (1.0, c[1], c[2]), compat=False)
+        rows = (np.asarray(lm_vertex)[:, None] * dim + np.arange(dim)[None, :]).flatten()
+        Jw = np.concatenate([Jw, c_land * J1[rows]], axis=0)
+    return Jw
+
+
 def nicp(P, nbr, wt, source, edges, target, tol, run, c=(C_FIT, C_RIGID, C_SMOOTH), history=None,
          compat=True, **lsq_kw):
     """nicp_3d.py:344-363: outer loop with scipy.optimize.leastsq (MINPACK lmder)

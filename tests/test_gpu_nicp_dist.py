@@ -25,9 +25,22 @@ def _problem(nx, ny, seed=5):
     return v, edges, tgt, nbr, wt, nn
 
 
-def _single(v, edges, nbr, wt, nn, opts):
+def _extension(v, edges):
+    """Row multipliers + landmarks of the extended energy (nicp_set_weights / nicp_set_landmarks), global arrays."""
+    rng = np.random.default_rng(17)
+    n, ne = v.shape[0], len(edges)
+    lm = rng.permutation(n)[:n // 6].astype(np.int32)
+    return dict(fit_w=rng.uniform(0.2, 2.0, n), rigid_w=rng.uniform(0.5, 1.5, n), edge_w=rng.uniform(0.3, 3.0, ne)), \
+        dict(vertex=lm, pos=v[lm] + 0.03 * rng.standard_normal((len(lm), 3)), c_land=5.0)
+
+
+def _single(v, edges, nbr, wt, nn, opts, ext=False):
     from icp_amd import nicp
     w = nicp.SparseWeights(nbr, wt, 3)
+    if ext:
+        wts, lms = _extension(v, edges)
+        w.set_weights(edges, **wts)
+        w.set_landmarks(edges, **lms)
     P0 = nicp.initial_params(v.shape[0], 3)
     P, st = nicp.solve(P0, w, v, edges, nn, C, compat=False, opts=opts)
     return P.cpu().numpy(), st
@@ -69,7 +82,11 @@ def _worker(rank, world, port, q, nx, ny, mode):
         from icp_amd import nicp_dist as nd
         v, edges, tgt, nbr, wt, nn = _problem(nx, ny)
         sh = nd.ShardedNICP(v, nbr, wt, edges, tgt)
-        if mode == "solve":
+        if mode == "solve_ext":
+            wts, lms = _extension(v, edges)
+            sh.set_weights(**wts)
+            sh.set_landmarks(**lms)
+        if mode in ("solve", "solve_ext"):
             st = sh.solve(sh.ctx.to_dev(sh.shard.localize(nn, 3)), C, TIGHT)
             out = dict(st=st)
         else:
@@ -128,6 +145,25 @@ def test_world2_solve_matches_single():
     np.testing.assert_allclose(res[0]["tail"], P_ref[n * 12:], rtol=1e-6, atol=1e-8)
     dd_ref = orc.deform(P_ref, nbr, wt, v)
     np.testing.assert_allclose(dd, dd_ref, rtol=1e-6, atol=1e-8)
+
+
+def test_world2_extended_energy_matches_single():
+    """Row multipliers and landmark rows through the sharded solve: every landmark row is counted by
+    exactly one rank, halo copies carry the multipliers of their fit rows."""
+    nx, ny = 13, 11
+    v, edges, tgt, nbr, wt, nn = _problem(nx, ny)
+    n = v.shape[0]
+    P_ref, st_ref = _single(v, edges, nbr, wt, nn, TIGHT, ext=True)
+    P_plain, st_plain = _single(v, edges, nbr, wt, nn, TIGHT)
+    assert abs(st_ref["err0"] - st_plain["err0"]) > 1e-3 * st_plain["err0"]      # the extension really changes the energy
+    res = _run_world(2, nx, ny, "solve_ext")
+    P, dd = _assemble(res, n)
+    st = res[0]["st"]
+    assert res[1]["st"] == st
+    print("single", st_ref, "sharded", st)
+    np.testing.assert_allclose(st["err0"], st_ref["err0"], rtol=1e-12)
+    np.testing.assert_allclose(st["err"], st_ref["err"], rtol=1e-9)
+    np.testing.assert_allclose(dd, orc.deform(P_ref, nbr, wt, v), rtol=1e-6, atol=1e-8)
 
 
 def test_world2_outer_loop_matches_single():

@@ -84,6 +84,49 @@ def test_sharded_operator_assembles_to_global(world):
     np.testing.assert_allclose(gg, want_grad, rtol=1e-10, atol=1e-9 * np.abs(want_grad).max())
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_extended_energy_assembles_to_global(world):
+    """Row multipliers and landmark rows (nicp_set_weights / nicp_set_landmarks) cut per rank by
+    Shard.local_weights / local_landmarks: energy, J^T J p and the gradient still assemble."""
+    v, edges, tgt, nbr, wt, P, nn = _mesh()
+    n, S, NG = v.shape[0], 12, 6
+    rng = np.random.default_rng(9)
+    fw, gw, ew = rng.uniform(0, 2, n), rng.uniform(0.5, 1.5, n), rng.uniform(0.2, 3, len(edges))
+    lm_v = rng.permutation(n)[:n // 5]
+    lm_p = v[lm_v] + 0.05 * rng.standard_normal((len(lm_v), 3))
+    c_land = 3.0
+    ext = dict(fit_w=fw, rigid_w=gw, edge_w=ew, lm_vertex=lm_v, lm_pos=lm_p, c_land=c_land)
+    J = orc.d_min_func_ext(P, nbr, wt, v, edges, nn, C, **ext)
+    r = orc.min_func_ext(P, nbr, wt, v, edges, nn, C, **ext)
+    p = rng.standard_normal(len(P))
+    want, want_grad = J.T @ (J @ p), J.T @ r
+    shards, owner = nd.make_shards(v, nbr, wt, edges, world)
+    got_v, got_tail, grad_v, grad_tail, energy, owned_lm = [], np.zeros(NG), [], np.zeros(NG), 0.0, 0
+    for s in shards:
+        nl = len(s.local_ids)
+        Pl, pl = s.local_params(P), s.local_params(p)
+        vl, nnl = s.localize(v, 3), s.localize(nn, 3)
+        f, g, e = s.local_weights(fw, gw, ew)
+        sel, lv, mask = s.local_landmarks(lm_v)
+        owned_lm += int(mask[len(s.row_mask):].sum()) // 3
+        extl = dict(fit_w=f, rigid_w=g, edge_w=e, lm_vertex=lv, lm_pos=lm_p[sel], c_land=c_land)
+        Jl = orc.d_min_func_ext(Pl, s.nbr, s.wt, vl, s.edges, nnl, C, **extl)
+        rl = orc.min_func_ext(Pl, s.nbr, s.wt, vl, s.edges, nnl, C, **extl)
+        assert len(rl) == len(mask)
+        energy += float(np.sum(mask * rl * rl))
+        yl = Jl @ pl
+        got_v.append((Jl.T @ yl)[:nl * S].reshape(nl, S))
+        got_tail += Jl[:, nl * S:].T @ (mask * yl)
+        grad_v.append((Jl.T @ rl)[:nl * S].reshape(nl, S))
+        grad_tail += Jl[:, nl * S:].T @ (mask * rl)
+    assert owned_lm == len(lm_v)                                                # every landmark row owned exactly once
+    np.testing.assert_allclose(energy, r @ r, rtol=1e-12)
+    got = np.concatenate([nd.assemble(shards, got_v, S).ravel(), got_tail])
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-9 * np.abs(want).max())
+    gg = np.concatenate([nd.assemble(shards, grad_v, S).ravel(), grad_tail])
+    np.testing.assert_allclose(gg, want_grad, rtol=1e-10, atol=1e-9 * np.abs(want_grad).max())
+
+
 def test_single_rank_shard_is_the_mesh():
     v, edges, tgt, nbr, wt, P, nn = _mesh(6, 5)
     shards, owner = nd.make_shards(v, nbr, wt, edges, 1)
