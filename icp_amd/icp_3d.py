@@ -83,15 +83,20 @@ def main(srcPath=None, tgtPath=None, out=None, tol=0.10, run=50):
         print("You must select 2 models")
         return None
     srcPath, tgtPath = sel
-    print("Source model is %s" % srcPath)
-    print("Target model is %s" % tgtPath)
+    print("Source model is %s" % meshio.PathName(srcPath))
+    print("Target model is %s" % meshio.PathName(tgtPath))
+    if not (meshio.IsMesh(srcPath) and meshio.IsMesh(tgtPath)):
+        print("Selected models are not a mesh")
+        return None
     srcPts = meshio.GetVertices(srcPath)
     tgtPts = meshio.GetVertices(tgtPath)
     print("Source mode has %d vertices" % srcPts.shape[0])
     print("Target mode has %d vertices" % tgtPts.shape[0])
     Trans = ICP(srcPts, tgtPts, tol, run)
-    meshio.ArrayToMMatrix(Trans)
-    if out is not None and meshio._is_file(srcPath):
+    t = meshio.ArrayToMMatrix(Trans)
+    if not meshio._is_file(srcPath):
+        meshio.ApplyToTransform(srcPath, t)          # inside Maya: icp_3d.py:154-157
+    elif out is not None:
         meshio.ModifyVertices(srcPath, meshio.apply_matrix(srcPts, Trans), out=out)
     return Trans
 

@@ -278,6 +278,27 @@ def ModifyVertices(path, dset, out=None):
     om.MFnMesh(path).setPoints([om.MPoint(*row) for row in dset], om.MSpace.kWorld)
 
 
+def IsMesh(path):
+    """The `hasFn(om.MFn.kMesh)` test of icp_3d.py:144 / nicp_3d.py:398; files always are."""
+    if _is_file(path):
+        return True
+    om = _maya()
+    return bool(path.hasFn(om.MFn.kMesh))
+
+
+def PathName(path):
+    """`partialPathName()` of a DAG path (icp_3d.py:142-143), or the file name."""
+    return path if _is_file(path) else path.partialPathName()
+
+
+def ApplyToTransform(path, t):
+    """icp_3d.py:154-157: post-multiply the transform node of a DAG path by the MMatrix t."""
+    om = _maya()
+    transform = om.MFnTransform(path)
+    m = transform.transformation().asMatrix()
+    transform.setTransformation(om.MTransformationMatrix(m * t))
+
+
 def ArrayToMMatrix(arr):
     """icp_3d.py:126-131: the 4x4 row-vector transform as an MMatrix inside Maya, else as the
     same nested tuple MMatrix is built from."""

@@ -1,7 +1,7 @@
 """Drop-in for the hot-path functions of the reference's nicp_3d.py (3-D non-rigid ICP,
 embedded deformation): same names, positional arguments and return shapes, computed by
-libicp_hip.so on an MI355X.  Maya glue (nicp_3d.py:25-47,368-457) is not part of this
-package.
+libicp_hip.so on an MI355X.  The Maya glue (nicp_3d.py:25-47,368-457) lives in
+icp_amd/meshio.py and icp_amd/maya_plugin.py.
 
 `w` is returned by Initialise as a SparseWeights object (the reference's dense N x N
 matrix has 4 non-zeros per column and cannot exist at 10k+ vertices); every function
@@ -117,8 +117,11 @@ def main(srcPath=None, tgtPath=None, out=None, tol=0.01, run=50):
         print("You must select 2 models")
         return None
     srcPath, tgtPath = sel
-    print("Source model is {0:s}".format(str(srcPath)))
-    print("Target model is {0:s}".format(str(tgtPath)))
+    print("Source model is {0:s}".format(str(meshio.PathName(srcPath))))
+    print("Target model is {0:s}".format(str(meshio.PathName(tgtPath))))
+    if not (meshio.IsMesh(srcPath) and meshio.IsMesh(tgtPath)):
+        print("Selected models are not a mesh")
+        return None
     srcPts, srcEdges = meshio.GetVerticesEdges(srcPath)
     tgtPts, tgtEdges = meshio.GetVerticesEdges(tgtPath)
     print("Source mode has {0:d} vertices, {1:d} edges".format(srcPts.shape[0], srcEdges.shape[0]))
@@ -128,7 +131,10 @@ def main(srcPath=None, tgtPath=None, out=None, tol=0.01, run=50):
     if out is None:
         return P0, w, nn
     newPts, P = NICP(P0, w, srcPts, srcEdges, tgtPts, tol, run)
-    meshio.ModifyVertices(srcPath, newPts, out=out)
+    if meshio._is_file(srcPath):
+        meshio.ModifyVertices(srcPath, newPts, out=out)
+    else:
+        meshio.ModifyVertices(srcPath, newPts)       # inside Maya: nicp_3d.py:409 (commented out there)
     return newPts, P
 
 
