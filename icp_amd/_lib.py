@@ -77,7 +77,7 @@ class SolveOpts(ctypes.Structure):
 class SolveStats(ctypes.Structure):
     """nicp_solve_stats of include/icp_hip.h"""
     _fields_ = [("err", c_dbl), ("err0", c_dbl), ("lm_iters", c_int), ("cg_iters", c_int), ("nfev", c_int),
-                ("info", c_int)]
+                ("info", c_int), ("graph_launches", c_int)]
 
 
 NICP_REFERENCE_COMPAT = 1

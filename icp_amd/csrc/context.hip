@@ -67,6 +67,11 @@ extern "C" int icp_ctx_destroy(icp_ctx *ctx) {
                            &ctx->sort_c,   &ctx->sort_d,    &ctx->defer};
     for (icp::Scratch *s : all)
         if (s->ptr) (void)hipFree(s->ptr);
+    if (ctx->side) {
+        (void)hipStreamSynchronize(ctx->side);
+        (void)hipStreamDestroy(ctx->side);
+    }
+    if (ctx->side_ev) (void)hipEventDestroy(ctx->side_ev);
     delete ctx;
     return ICP_OK;
 }

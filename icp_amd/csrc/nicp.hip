@@ -58,6 +58,7 @@ namespace icp {
 
 constexpr int NB = 256;
 constexpr int KNN_TILE = 512;
+constexpr int kCgChunk = 50;  // CG iterations between two host reads of the stop flag (= one hipGraph replay)
 
 template <int DIM>
 struct Lay {
@@ -787,62 +788,21 @@ __global__ __launch_bounds__(NB) void final_sum_kernel(const double *__restrict_
 }
 
 // CG bookkeeping on the device (no host round trip inside the iteration)
-__global__ void cg_alpha_kernel(Scal *s) {
-    if (s->stop) return;
-    s->alpha = s->pAp > 0 ? s->rz / s->pAp : 0.0;
-    if (!(s->pAp > 0)) s->stop = 2;  // breakdown (non-positive curvature / NaN)
-}
-__global__ void cg_beta_kernel(Scal *s, double tol2) {
-    if (s->stop) return;
-    s->beta = s->rz_new / s->rz;
-    s->rz = s->rz_new;
-    s->iters += 1;
-    if (!(s->rr > tol2 * s->rr0)) s->stop = 1;
-}
-// x += alpha p; r -= alpha Ap; z = r / m; partials of r.z and r.r
-__global__ __launch_bounds__(NB) void cg_update_kernel(const Scal *__restrict__ s, double *__restrict__ x,
-                                                       double *__restrict__ r, double *__restrict__ z,
-                                                       const double *__restrict__ p, const double *__restrict__ Ap,
-                                                       const double *__restrict__ minv, int64_t len,
-                                                       double *__restrict__ part_rz, double *__restrict__ part_rr) {
-    double a = 0.0, b = 0.0;
-    if (!s->stop) {
-        const double alpha = s->alpha;
-        for (int64_t i = (int64_t)blockIdx.x * NB + threadIdx.x; i < len; i += (int64_t)gridDim.x * NB) {
-            x[i] += alpha * p[i];
-            const double ri = r[i] - alpha * Ap[i];
-            r[i] = ri;
-            const double zi = ri * minv[i];
-            z[i] = zi;
-            a += ri * zi;
-            b += ri * ri;
-        }
-    }
-    block_sum_to(a, part_rz);
-    __syncthreads();
-    block_sum_to(b, part_rr);
-}
-__global__ __launch_bounds__(NB) void cg_dir_kernel(const Scal *__restrict__ s, double *__restrict__ p,
-                                                    const double *__restrict__ z, int64_t len) {
-    if (s->stop) return;
-    const double beta = s->beta;
-    for (int64_t i = (int64_t)blockIdx.x * NB + threadIdx.x; i < len; i += (int64_t)gridDim.x * NB)
-        p[i] = z[i] + beta * p[i];
-}
 // generic elementwise helpers
 __global__ __launch_bounds__(NB) void axpby_kernel(double a, const double *__restrict__ x, double b,
                                                    const double *__restrict__ y, double *__restrict__ out, int64_t len) {
     for (int64_t i = (int64_t)blockIdx.x * NB + threadIdx.x; i < len; i += (int64_t)gridDim.x * NB)
         out[i] = a * x[i] + (y ? b * y[i] : 0.0);
 }
-// MINPACK-style scaling: d2 = max(d2_prev, colnorm2) (zero columns -> 1); minv = 1/(colnorm2 + lam d2)
+// MINPACK-style scaling: d2 = max(d2_prev, colnorm2) (zero columns -> 1); lamd2 = lam d2 (what the CG
+// operator adds: kept as a vector so that the kernel arguments of a CG iteration do not change with lam)
 __global__ __launch_bounds__(NB) void scaling_kernel(const double *__restrict__ col2, double *__restrict__ d2,
-                                                     double *__restrict__ minv, double lam, int first, int64_t len) {
+                                                     double *__restrict__ lamd2, double lam, int first, int64_t len) {
     for (int64_t i = (int64_t)blockIdx.x * NB + threadIdx.x; i < len; i += (int64_t)gridDim.x * NB) {
         double c = col2[i];
         double d = first ? (c > 0 ? c : 1.0) : (d2[i] > c ? d2[i] : c);
         d2[i] = d;
-        minv[i] = 1.0 / (c + lam * d);
+        lamd2[i] = lam * d;
     }
 }
 
@@ -860,6 +820,7 @@ struct Coarse {
     double E[NZMAX * NZMAX];
     double ztr[NZMAX], y[NZMAX];
     double tail_minv[6];
+    double tol2;  // square of the relative residual at which this CG solve stops (device-resident: may change per LM step)
 };
 
 // the NG per-vertex zero-stiffness modes at vertex j: z[k][0..S)
@@ -1156,8 +1117,7 @@ __global__ __launch_bounds__(1024) void cg_sum_alpha_kernel(const double *__rest
 
 // tail update, coarse solve y = Einv Z^T r, r.z, beta, stop test.  tot[0] r.zb, tot[1] r.r, tot[2..2+ng) Z_v^T r
 __device__ __forceinline__ void coarse_logic(const double *tot, int ng, double *x_tail, double *r_tail, double *zb_tail,
-                                             const double *p_tail, const double *Ap_tail, Coarse *coarse, Scal *s, double tol2,
-                                             int init) {
+                                             const double *p_tail, const double *Ap_tail, Coarse *coarse, Scal *s, int init) {
     const int tid = threadIdx.x;
     const int stop = s->stop;  // uniform: only thread 0 writes it, at the very end
     if (stop) return;
@@ -1202,23 +1162,23 @@ __device__ __forceinline__ void coarse_logic(const double *tot, int ng, double *
         s->beta = rz / s->rz;
         s->rz = rz;
         s->iters += 1;
-        if (!(rr > tol2 * s->rr0)) s->stop = 1;
+        if (!(rr > coarse->tol2 * s->rr0)) s->stop = 1;
     }
 }
 __global__ __launch_bounds__(64) void cg_coarse_logic_kernel(const double *__restrict__ tot, int ng, double *__restrict__ x_tail,
                                                             double *__restrict__ r_tail, double *__restrict__ zb_tail,
                                                             const double *__restrict__ p_tail, const double *__restrict__ Ap_tail,
-                                                            Coarse *__restrict__ coarse, Scal *__restrict__ s, double tol2, int init) {
-    coarse_logic(tot, ng, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s, tol2, init);
+                                                            Coarse *__restrict__ coarse, Scal *__restrict__ s, int init) {
+    coarse_logic(tot, ng, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s, init);
 }
 __global__ __launch_bounds__(1024) void cg_sum_coarse_kernel(const double *__restrict__ partial, int nb, unsigned mask,
                                                              double *__restrict__ tot, int ng, double *__restrict__ x_tail,
                                                              double *__restrict__ r_tail, double *__restrict__ zb_tail,
                                                              const double *__restrict__ p_tail, const double *__restrict__ Ap_tail,
-                                                             Coarse *__restrict__ coarse, Scal *__restrict__ s, double tol2, int init) {
+                                                             Coarse *__restrict__ coarse, Scal *__restrict__ s, int init) {
     block_rows_sum(partial, nb, mask, tot, 0);
     __syncthreads();
-    coarse_logic(tot, ng, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s, tol2, init);
+    coarse_logic(tot, ng, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s, init);
 }
 
 // tot[slot] += sum_k a[k] b[k] (w ? w[k] : 1) over the ng replicated tail entries (added on one rank only)
@@ -1464,7 +1424,7 @@ struct Work {
     double *partial;                       // kMaxPartials * kSumSlots
     double *pre, *dd;                      // [n,dim]
     double *r, *r_trial, *y;               // nr
-    double *grad, *col2, *d2, *minv;       // np
+    double *grad, *col2, *d2, *lamd2;      // np
     double *delta, *rcg, *z, *pcg, *Ap;    // np
     double *x_trial;                       // np
     double *binv;                          // n * S(S+1)/2: inverted diagonal blocks
@@ -1507,7 +1467,7 @@ static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     w.r = p; p += d.nr;
     w.r_trial = p; p += d.nr;
     w.y = p; p += d.nr;
-    double **np_bufs[] = {&w.grad, &w.col2, &w.d2, &w.minv, &w.delta, &w.rcg, &w.z, &w.pcg, &w.Ap, &w.x_trial};
+    double **np_bufs[] = {&w.grad, &w.col2, &w.d2, &w.lamd2, &w.delta, &w.rcg, &w.z, &w.pcg, &w.Ap, &w.x_trial};
     for (double **b : np_bufs) {
         *b = p;
         p += d.np;
@@ -2049,7 +2009,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
     const double *c = c3_host;
     Scal hs;
     double ht[8];
-    nicp_solve_stats stt = {0, 0, 0, 0, 0, 0};
+    nicp_solve_stats stt = {0, 0, 0, 0, 0, 0, 0};
     const int nbp = grid_for(d.np);
     const int64_t nown = par_in.nown;
 
@@ -2084,6 +2044,22 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
     double lam = o.lambda0, nu = 2.0;
     int info = 0;
     bool first_scaling = true;
+    // hipGraph replay of the CG iterations: single GPU only (the sharded iteration calls back into the host).
+    // Default: meshes of >= 1024 vertices; ICP_NICP_GRAPH=0 / 1 forces it off / on.
+    struct CgGraph {
+        hipGraphExec_t exec = nullptr;
+        bool failed = false;
+        ~CgGraph() {
+            if (exec) (void)hipGraphExecDestroy(exec);
+        }
+    } cg;
+    bool use_graph = !par.sharded() && d.n >= 1024;
+    if (const char *e = getenv("ICP_NICP_GRAPH")) use_graph = !par.sharded() && atoi(e) != 0;
+    if (use_graph) {
+        if (!ctx->side && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) use_graph = false;
+        if (use_graph && !ctx->side_ev && hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming) != hipSuccess) use_graph = false;
+        if (!use_graph) (void)hipGetLastError();
+    }
     for (int it = 0; it < o.max_lm_iters && !info; ++it) {
         stt.lm_iters = it + 1;
         if (!(f2 == f2) || std::isinf(f2)) {
@@ -2099,12 +2075,13 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
         }
         if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, r_for_grad, nullptr, nullptr, 0.0, w.grad, false)) return rc;
         if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.r, nullptr, nullptr, 0.0, w.col2, true)) return rc;
+        const double cg_tol_now = o.cg_tol;
         bool accepted = false;
         bool relinearise = false;
         while (!accepted && !info) {
             if (relinearise)  // a rejected trial left the linearisation state at x_trial
                 if (int rc = linearise(ctx, g, w, x, v)) return rc;
-            hipLaunchKernelGGL(scaling_kernel, dim3(nbp), dim3(NB), 0, st, w.col2, w.d2, w.minv, lam, first_scaling ? 1 : 0, d.np);
+            hipLaunchKernelGGL(scaling_kernel, dim3(nbp), dim3(NB), 0, st, w.col2, w.d2, w.lamd2, lam, first_scaling ? 1 : 0, d.np);
             first_scaling = false;
             // ---- two-level preconditioner for (J^T J + lam D^2): inverted vertex blocks + coarse space
             const int nbv = vgrid(g, nown), nbt = vgrid(g, d.n + d.NG), nz = 2 * d.NG;
@@ -2139,6 +2116,9 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 ICP_HIP_CHECK(hipStreamSynchronize(st));
                 if (!invert_spd(E, nz, Einv)) std::memset(Einv, 0, sizeof(Einv));  // fall back to the block level alone
                 ICP_HIP_CHECK(hipMemcpyAsync(w.coarse->Einv, Einv, sizeof(double) * nz * nz, hipMemcpyHostToDevice, st));
+                const double tol2 = cg_tol_now * cg_tol_now;
+                ICP_HIP_CHECK(hipMemcpyAsync(&w.coarse->tol2, &tol2, sizeof(double), hipMemcpyHostToDevice, st));
+                ICP_HIP_CHECK(hipStreamSynchronize(st));  // both sources are on this stack frame
             }
             // ---- preconditioned CG on (J^T J + lam D^2) delta = -grad
             ICP_HIP_CHECK(hipMemsetAsync(w.delta, 0, d.np * sizeof(double), st));
@@ -2152,12 +2132,12 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 if (!par.sharded()) {
                     hipLaunchKernelGGL(cg_sum_coarse_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, (1u << (2 + d.NG)) - 1u,
                                        par.tot, d.NG, x_tail, r_tail, zb_tail, (const double *)p_tail, (const double *)Ap_tail, w.coarse,
-                                       w.scal, o.cg_tol * o.cg_tol, init);
+                                       w.scal, init);
                 } else {
                     hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, (1u << (2 + d.NG)) - 1u, par.tot, 0);
                     if (int rc = allreduce(par, 2 + d.NG)) return rc;
                     hipLaunchKernelGGL(cg_coarse_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, x_tail, r_tail, zb_tail,
-                                       (const double *)p_tail, (const double *)Ap_tail, w.coarse, w.scal, o.cg_tol * o.cg_tol, init);
+                                       (const double *)p_tail, (const double *)Ap_tail, w.coarse, w.scal, init);
                 }
                 if (g->dim == 3) hipLaunchKernelGGL(cg_dir_prec_kernel<3>, dim3(nbt), dim3(g->vb), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown, w.st);
                 else hipLaunchKernelGGL(cg_dir_prec_kernel<2>, dim3(nbt), dim3(g->vb), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown, w.st);
@@ -2165,26 +2145,64 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             };
             if (int rc = precondition(1)) return rc;  // alpha = 0: z = M^-1 r, rz, rr0, p = z
             ICP_HIP_CHECK(hipGetLastError());
-            int cg_done = 0;
-            for (int ci = 0; ci < o.max_cg_iters && !cg_done;) {
-                const int chunk = std::min(50, o.max_cg_iters - ci);
-                for (int k = 0; k < chunk; ++k) {
+            // `count` CG iterations.  The damping enters as the vector lam*D^2 (w.lamd2, multiplier 1.0: the same
+            // bits as lam * d2 * p), so no kernel argument below changes during a solve and the single-GPU
+            // path can replay kCgChunk iterations as one hipGraph (6 launches each, launch-bound on small meshes).
+            const double *lamd2_tail = w.lamd2 + d.n * d.S;
+            auto cg_iterations = [&](int count) -> int {
+                for (int k = 0; k < count; ++k) {
                     if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.pcg, w.y, 1)) return rc;
-                    if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.y, w.d2, w.pcg, lam, w.Ap, false, false)) return rc;
+                    if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.y, w.lamd2, w.pcg, 1.0, w.Ap, false, false)) return rc;
                     if (!par.sharded()) {
                         hipLaunchKernelGGL(cg_sum_alpha_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask | (1u << 8),
-                                           par.tot, d.NG, d2_tail, (const double *)p_tail, lam, Ap_tail, w.scal);
+                                           par.tot, d.NG, lamd2_tail, (const double *)p_tail, 1.0, Ap_tail, w.scal);
                     } else {
                         hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask | (1u << 8), par.tot, 0);
                         if (int rc = allreduce(par, 9)) return rc;
-                        hipLaunchKernelGGL(cg_alpha_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, d2_tail,
-                                           (const double *)p_tail, lam, Ap_tail, w.scal);
+                        hipLaunchKernelGGL(cg_alpha_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, lamd2_tail,
+                                           (const double *)p_tail, 1.0, Ap_tail, w.scal);
                     }
                     if (int rc = precondition(0)) return rc;
                 }
                 ICP_HIP_CHECK(hipGetLastError());
+                return ICP_OK;
+            };
+            if (use_graph && !cg.exec && !cg.failed) {
+                // capture once per solve, on the context's side stream (st may be the legacy default stream)
+                hipStream_t user = ctx->stream;
+                ctx->stream = st = ctx->side;
+                hipGraph_t captured = nullptr;
+                int rc = ICP_OK;
+                hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+                if (e == hipSuccess) {
+                    rc = cg_iterations(kCgChunk);
+                    e = hipStreamEndCapture(st, &captured);
+                }
+                ctx->stream = st = user;
+                if (e == hipSuccess && !rc) e = hipGraphInstantiate(&cg.exec, captured, nullptr, nullptr, 0);
+                if (captured) (void)hipGraphDestroy(captured);
+                if (rc) return rc;
+                if (e != hipSuccess) {  // no graphs on this runtime / stream: plain launches from here on
+                    (void)hipGetLastError();
+                    cg.exec = nullptr;
+                    cg.failed = true;
+                }
+            }
+            int cg_done = 0;
+            for (int ci = 0; ci < o.max_cg_iters && !cg_done;) {
+                const int chunk = std::min(kCgChunk, o.max_cg_iters - ci);
+                if (cg.exec && chunk == kCgChunk) {
+                    ICP_HIP_CHECK(hipEventRecord(ctx->side_ev, st));
+                    ICP_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));
+                    ICP_HIP_CHECK(hipGraphLaunch(cg.exec, ctx->side));
+                    ICP_HIP_CHECK(hipMemcpyAsync(&hs, w.scal, sizeof(Scal), hipMemcpyDeviceToHost, ctx->side));
+                    ICP_HIP_CHECK(hipStreamSynchronize(ctx->side));  // also orders the side stream's work before anything queued on st next
+                    stt.graph_launches++;
+                } else {
+                    if (int rc = cg_iterations(chunk)) return rc;
+                    if (int rc = read_scal(ctx, w.scal, hs)) return rc;
+                }
                 ci += chunk;
-                if (int rc = read_scal(ctx, w.scal, hs)) return rc;
                 cg_done = hs.stop;
             }
             stt.cg_iters += hs.iters;

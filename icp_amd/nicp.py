@@ -254,7 +254,8 @@ def solve(P, w, source, edges, nn, c, compat=True, opts=None, ctx=None):
     st = _lib.SolveStats()
     ctx.call("nicp_solve", g, ptr(Pd), ptr(v), ptr(nnd), _c3(c), 1 if compat else 0,
              ctypes.byref(o) if o is not None else None, ctypes.byref(st))
-    return Pd, dict(err=st.err, err0=st.err0, lm_iters=st.lm_iters, cg_iters=st.cg_iters, nfev=st.nfev, info=st.info)
+    return Pd, dict(err=st.err, err0=st.err0, lm_iters=st.lm_iters, cg_iters=st.cg_iters, nfev=st.nfev, info=st.info,
+                    graph_launches=st.graph_launches)
 
 
 def nicp(P, w, source, edges, target, tol, run, c, compat=True, opts=None, history=None, ctx=None):

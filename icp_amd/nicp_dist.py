@@ -328,7 +328,8 @@ class ShardedNICP:
             if self.comm.error is not None:
                 raise self.comm.error
             raise
-        return dict(err=st.err, err0=st.err0, lm_iters=st.lm_iters, cg_iters=st.cg_iters, nfev=st.nfev, info=st.info)
+        return dict(err=st.err, err0=st.err0, lm_iters=st.lm_iters, cg_iters=st.cg_iters, nfev=st.nfev, info=st.info,
+                    graph_launches=st.graph_launches)
 
     def match(self):
         """Deform -> Match for the local rows against the replicated target."""

@@ -229,13 +229,16 @@ typedef struct nicp_solve_stats {
     double err0; /* ... at the initial P */
     int lm_iters, cg_iters, nfev;
     int info;    /* 1 ftol, 2 xtol, 3 both, 4 gtol, 5 iteration limit */
+    int graph_launches; /* 50-iteration CG chunks replayed as one hipGraph (0: plain launches; see ICP_NICP_GRAPH) */
 } nicp_solve_stats;
 
 /* The optimize.leastsq call of nicp_3d.py:351 / nicp_row.py:246: minimise |MinFunc(P)|^2 from
  * P_inout with correspondences nn fixed.  Levenberg-Marquardt; each step solves
  * (J^T J + lambda D^2) delta = -J^T r by conjugate gradients on the matrix-free operators above,
  * preconditioned by the inverted per-vertex blocks plus a 12-dimensional (6 in 2-D) coarse space
- * of the modes the stiffness terms cannot see.  opts_host may be NULL; stats_host may be NULL.  Synchronises. */
+ * of the modes the stiffness terms cannot see.  On one GPU the CG iterations are replayed 50 at a time
+ * as a hipGraph captured once per solve (meshes of >= 1024 vertices; environment ICP_NICP_GRAPH=0/1
+ * forces it off/on; same kernels, same bits).  opts_host may be NULL; stats_host may be NULL.  Synchronises. */
 int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, const double *nn,
                const double *c3_host, unsigned flags, const nicp_solve_opts *opts_host,
                nicp_solve_stats *stats_host);

@@ -237,3 +237,36 @@ def test_knn_grid_equals_full_scan(mods, kind, monkeypatch):
     si, sd = nic.knn(v, v, 6)                       # the Initialise case: every point against the set itself
     oi, od = c_oracle.knn_rows(v, 6)
     assert np.array_equal(si.cpu().numpy(), oi) and np.array_equal(sd.cpu().numpy(), od)
+
+
+def test_cg_graph_replay_is_bit_identical(mods, monkeypatch):
+    """The hipGraph replay of the CG iterations (single GPU) launches the same kernels with the same
+    arguments: parameters, energies and iteration counts must not change by a bit."""
+    v, edges, tgt = orc.make_grid_mesh(40, 36, seed=11)       # 1440 vertices: above the default threshold
+    nic = mods["nicp"]
+    w = nic.knn_weights(v)
+    nn = tgt[c_oracle.match_idx(v, tgt)[0]]
+    P0 = nic.initial_params(len(v), 3)
+    opts = dict(max_lm_iters=3, cg_tol=1e-8)
+    out = {}
+    for mode in ("0", "1", None):
+        if mode is None:
+            monkeypatch.delenv("ICP_NICP_GRAPH", raising=False)
+        else:
+            monkeypatch.setenv("ICP_NICP_GRAPH", mode)
+        P, st = nic.solve(P0, w, v, edges, nn, C, compat=False, opts=opts)
+        out[mode] = (P.cpu().numpy(), st)
+    assert out["0"][1]["graph_launches"] == 0
+    assert out["1"][1]["graph_launches"] > 0 and out[None][1]["graph_launches"] == out["1"][1]["graph_launches"]
+    assert out["1"][1]["cg_iters"] >= 50
+    for k in ("err", "err0", "lm_iters", "cg_iters", "nfev", "info"):
+        assert out["0"][1][k] == out["1"][1][k] == out[None][1][k]
+    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][0], out[None][0])
+    # small meshes stay on plain launches by default, and can be forced onto the graph
+    g = golden("nicp_step_60")
+    monkeypatch.delenv("ICP_NICP_GRAPH", raising=False)
+    Pa, sa = nic.solve(g["P0"], g["w"], g["v"], g["edges"], g["nn"], C, compat=False)
+    monkeypatch.setenv("ICP_NICP_GRAPH", "1")
+    Pb, sb = nic.solve(g["P0"], g["w"], g["v"], g["edges"], g["nn"], C, compat=False)
+    assert sa["graph_launches"] == 0 and sb["graph_launches"] > 0
+    assert np.array_equal(Pa.cpu().numpy(), Pb.cpu().numpy())
