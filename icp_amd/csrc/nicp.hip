@@ -59,6 +59,7 @@ namespace icp {
 constexpr int NB = 256;
 constexpr int KNN_TILE = 512;
 constexpr int kCgChunk = 50;  // CG iterations between two host reads of the stop flag (= one hipGraph replay)
+static_assert(kCgChunk % 2 == 0, "the fused CG kernels alternate a parity that must restart at 0 with every chunk");
 
 template <int DIM>
 struct Lay {
@@ -1064,6 +1065,40 @@ __device__ __forceinline__ void block_rows_sum(const double *__restrict__ partia
         if (lane == 0) tot[off + k] = a;
     }
 }
+// The same sums (same order, same bits) taken by EVERY block of a consumer kernel into its LDS.  Lets the
+// single-GPU CG iteration drop its two single-block sum+logic launches.
+template <unsigned MASK>
+__device__ __forceinline__ void block_rows_sum_lds(const double *__restrict__ partial, int nb, double *out_lds) {
+    // first wave only; four rows per lane in flight (every load issued before the first add: one memory latency for
+    // up to 256 rows), accumulation per lane in ascending row order, then the wave sum: block_rows_sum's order
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    double acc[kSumSlots];
+#pragma unroll
+    for (int k = 0; k < kSumSlots; ++k) acc[k] = 0.0;
+    for (int b0 = lane; b0 < nb; b0 += 256) {
+        double val[4][kSumSlots];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + 64 * q;
+            const double *row = partial + (int64_t)(b < nb ? b : b0) * kSumSlots;
+#pragma unroll
+            for (int k = 0; k < kSumSlots; ++k)
+                if ((MASK >> k) & 1u) val[q][k] = row[k];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < kSumSlots; ++k)
+                if (((MASK >> k) & 1u) && b0 + 64 * q < nb) acc[k] += val[q][k];
+    }
+#pragma unroll
+    for (int k = 0; k < kSumSlots; ++k)
+        if ((MASK >> k) & 1u) {
+            const double t = wave_sum(acc[k]);
+            if (lane == 0) out_lds[k] = t;
+        }
+}
 __global__ __launch_bounds__(1024) void rows_sum_kernel(const double *__restrict__ partial, int nb, unsigned mask,
                                                         double *__restrict__ tot, int off) {
     block_rows_sum(partial, nb, mask, tot, off);
@@ -1156,6 +1191,7 @@ __device__ __forceinline__ void coarse_logic(const double *tot, int ng, double *
     s->rr = rr;
     if (init) {
         s->rz = rz;
+        s->tmp[0] = rz;  // the fused kernels keep r.z in tmp[parity of the iteration] (see FusedCg)
         s->rr0 = rr;
         s->beta = 0.0;
     } else {
@@ -1227,19 +1263,82 @@ __global__ __launch_bounds__(NB) void dot_owned_kernel(const double *__restrict_
 
 // x += alpha p; r -= alpha Ap; zb = Binv r (per vertex); partials: r.zb, r.r, Z^T r.
 // Only the nown owned vertices are updated (halo copies [nown, n) are refreshed by the exchange).
-template <int DIM>
-__global__ __launch_bounds__(NB) void cg_update_prec_kernel(const Scal *__restrict__ s, const double *__restrict__ P,
+// FUSED (single GPU): the two single-block "sum the block partials, then scalar logic" launches of an iteration
+// are folded into their consumers -- every block of cg_update_prec_kernel sums the J^T kernel's partials and
+// derives alpha itself, every block of cg_dir_prec_kernel sums the update kernel's partials and solves the
+// coarse system itself; block 0 alone writes the shared state, and nothing a block reads is written by another
+// block of the same launch: r.z alternates between Scal::tmp[0] and tmp[1] by iteration parity, the tail
+// entries are advanced in the update kernel (which does not read them elsewhere) and only read in the
+// direction kernel, and the two kernels use separate partial buffers.  A block that sees the stop flag set by
+// block 0 of its own launch skips work nobody reads any more.  Same arithmetic in the same order as the
+// unfused path: results are bit-identical.
+struct FusedCg {
+    const double *in_partial;  // block partials to sum: of the J^T kernel (update) / of the update kernel (direction)
+    int nb;
+    const double *lamd2_tail;
+    double *x_tail, *r_tail, *zb_tail, *Ap_tail;
+    const double *p_tail;
+    int parity;
+};
+
+template <int DIM, bool FUSED>
+__global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s, const double *__restrict__ P,
                                                            const double *__restrict__ v, int64_t n,
                                                            double *__restrict__ x, double *__restrict__ r,
                                                            double *__restrict__ zb, const double *__restrict__ p,
                                                            const double *__restrict__ Ap, const double *__restrict__ binv,
-                                                           double *__restrict__ partial, int64_t nown, Strides st) {
+                                                           double *__restrict__ partial, int64_t nown, Strides st,
+                                                           const Coarse *__restrict__ coarse, FusedCg f) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc[2 + NG];
     for (int k = 0; k < 2 + NG; ++k) acc[k] = 0.0;
-    if (j < nown && !s->stop) {
-        const double alpha = s->alpha;
+    double alpha_blk = 0.0;
+    bool stop_blk;
+    if constexpr (FUSED) {
+        __shared__ double tot_s[kSumSlots];
+        __shared__ double alpha_sh;
+        __shared__ int stop_sh;
+        block_rows_sum_lds<((1u << NG) - 1u) | (1u << 8)>(f.in_partial, f.nb, tot_s);
+        __syncthreads();
+        if (threadIdx.x == 0) {  // alpha_logic, by every block for itself
+            int stop = s->stop;
+            double alpha = 0.0;
+            if (!stop) {
+                double pap = tot_s[8], apt[NG];
+                for (int k = 0; k < NG; ++k) {
+                    const double val = tot_s[k] + f.lamd2_tail[k] * f.p_tail[k];
+                    apt[k] = val;
+                    pap += val * f.p_tail[k];
+                }
+                alpha = pap > 0 ? s->tmp[f.parity] / pap : 0.0;
+                if (!(pap > 0)) stop = 2;  // breakdown (non-positive curvature / NaN)
+                if (blockIdx.x == 0) {
+                    s->pAp = pap;
+                    s->alpha = alpha;
+                    if (stop) s->stop = 2;
+                    for (int k = 0; k < NG; ++k) {
+                        f.Ap_tail[k] = apt[k];
+                        if (stop) continue;
+                        f.x_tail[k] += alpha * f.p_tail[k];  // the tail's share of the update (coarse_logic does it when unfused)
+                        const double rt = f.r_tail[k] - alpha * apt[k];
+                        f.r_tail[k] = rt;
+                        f.zb_tail[k] = rt * coarse->tail_minv[k];
+                    }
+                }
+            }
+            alpha_sh = alpha;
+            stop_sh = stop;
+        }
+        __syncthreads();
+        alpha_blk = alpha_sh;
+        stop_blk = stop_sh != 0;
+    } else {
+        stop_blk = s->stop != 0;
+        alpha_blk = s->alpha;
+    }
+    if (j < nown && !stop_blk) {
+        const double alpha = alpha_blk;
         // every load first, every store last: with run-time strides the compiler cannot tell x[o_e] from
         // x[o_e'] and would otherwise wait for each store before the next load (12 round trips in a row)
         double xj[S], rj[S], pj[S], apj[S], zj[S], Pj_[S], vj_[DIM];
@@ -1302,15 +1401,72 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(const Scal *__restri
 }
 
 // z = zb + Z y; p = z + beta p
-template <int DIM>
-__global__ __launch_bounds__(NB) void cg_dir_prec_kernel(const Scal *__restrict__ s, const Coarse *__restrict__ coarse,
+template <int DIM, bool FUSED>
+__global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, const Coarse *__restrict__ coarse,
                                                         const double *__restrict__ P, const double *__restrict__ v, int64_t n,
                                                         const double *__restrict__ zb, double *__restrict__ p, int64_t nown,
-                                                        Strides st) {
+                                                        Strides st, FusedCg f) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
-    if (s->stop) return;
+    __shared__ double y_s[NZMAX];
+    double beta;
+    if constexpr (FUSED) {
+        constexpr int nz = 2 * NG;
+        __shared__ double tot_s[kSumSlots], ztr_s[NZMAX], acc_s[2];
+        __shared__ double beta_sh;
+        __shared__ int stop_sh;
+        block_rows_sum_lds<(1u << (2 + NG)) - 1u>(f.in_partial, f.nb, tot_s);
+        __syncthreads();
+        if (threadIdx.x == 0) {  // coarse_logic, by every block for itself (the tails were advanced by the update kernel)
+            const int stop = s->stop;
+            if (!stop) {
+                double rz = tot_s[0], rr = tot_s[1];
+                for (int k = 0; k < NG; ++k) {
+                    const double rt = f.r_tail[k], zt = f.zb_tail[k];
+                    rz += rt * zt;
+                    rr += rt * rt;
+                    ztr_s[k] = tot_s[2 + k];
+                    ztr_s[NG + k] = rt;
+                }
+                acc_s[0] = rz;
+                acc_s[1] = rr;
+            }
+            stop_sh = stop;
+        }
+        __syncthreads();
+        if (!stop_sh && threadIdx.x < nz) {
+            double y = 0.0;
+            for (int b = 0; b < nz; ++b) y += coarse->Einv[threadIdx.x * nz + b] * ztr_s[b];
+            y_s[threadIdx.x] = y;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && !stop_sh) {
+            double rz = acc_s[0];
+            const double rr = acc_s[1];
+            for (int a = 0; a < nz; ++a) rz += ztr_s[a] * y_s[a];
+            const double bt = rz / s->tmp[f.parity];
+            const bool done = !(rr > coarse->tol2 * s->rr0);
+            if (blockIdx.x == 0) {
+                s->rz_new = rz;
+                s->rr = rr;
+                s->beta = bt;
+                s->rz = rz;
+                s->tmp[f.parity ^ 1] = rz;
+                s->iters += 1;
+                if (done) s->stop = 1;
+            }
+            beta_sh = bt;
+            if (done) stop_sh = 1;
+        }
+        __syncthreads();
+        if (stop_sh) return;  // uniform over the block
+        beta = beta_sh;
+    } else {
+        if (s->stop) return;
+        beta = s->beta;
+        if (threadIdx.x < 2 * NG) y_s[threadIdx.x] = coarse->y[threadIdx.x];
+        __syncthreads();
+    }
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const double beta = s->beta;
     if (j < n) {
         if (j >= nown) return;  // halo copy
         double z[NG][S], Pj_[S], vj_[DIM], zbj[S], pj[S], yk[NG];
@@ -1324,7 +1480,7 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(const Scal *__restrict_
 #pragma unroll
         for (int c = 0; c < DIM; ++c) vj_[c] = v[j * st.vj + c * st.vc];
 #pragma unroll
-        for (int k = 0; k < NG; ++k) yk[k] = coarse->y[k];
+        for (int k = 0; k < NG; ++k) yk[k] = y_s[k];
         zmodes<DIM>(Pj_, vj_, z);
 #pragma unroll
         for (int e = 0; e < S; ++e) {
@@ -1337,7 +1493,7 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(const Scal *__restrict_
         for (int e = 0; e < S; ++e) p[j * st.pj + e * st.pe] = pj[e];
     } else if (j < n + NG) {
         const int k = (int)(j - n);
-        p[n * S + k] = zb[n * S + k] + coarse->y[NG + k] + beta * p[n * S + k];
+        p[n * S + k] = zb[n * S + k] + y_s[NG + k] + beta * p[n * S + k];
     }
 }
 
@@ -1421,7 +1577,7 @@ static Dims dims_of(const nicp_graph *g) {
 struct Work {
     Globals *glob;
     Scal *scal;
-    double *partial;                       // kMaxPartials * kSumSlots
+    double *partial, *partial2;            // kMaxPartials * kSumSlots each (J^T kernel / CG update kernel)
     double *pre, *dd;                      // [n,dim]
     double *r, *r_trial, *y;               // nr
     double *grad, *col2, *d2, *lamd2;      // np
@@ -1440,7 +1596,7 @@ static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     const Dims d = dims_of(g);
     const size_t small = 1024;  // Globals + Scal + Coarse, in doubles (generous)
     const size_t tri = (size_t)d.S * (d.S + 1) / 2;
-    const size_t need = small + (size_t)kMaxPartials * kSumSlots + 4 * (size_t)d.n * d.dim + 4 * (size_t)d.nr + 11 * (size_t)d.np +
+    const size_t need = small + 2 * (size_t)kMaxPartials * kSumSlots + 4 * (size_t)d.n * d.dim + 4 * (size_t)d.nr + 11 * (size_t)d.np +
                         (size_t)d.n * tri + 64;
     if (g->ws_doubles < need) {
         if (g->ws) {
@@ -1462,6 +1618,7 @@ static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     static_assert(sizeof(Globals) <= 256 * 8 && sizeof(Scal) <= 256 * 8 && sizeof(Coarse) <= 384 * 8, "small area layout");
     p += small;
     w.partial = p; p += (size_t)kMaxPartials * kSumSlots;
+    w.partial2 = p; p += (size_t)kMaxPartials * kSumSlots;
     w.pre = p; p += (size_t)d.n * d.dim;
     w.dd = p; p += (size_t)d.n * d.dim;
     w.r = p; p += d.nr;
@@ -2053,6 +2210,10 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             if (exec) (void)hipGraphExecDestroy(exec);
         }
     } cg;
+    // fused sum+logic prologues pay on small meshes only (10 k vertices: +3 %; 200 k: -5 %, 784 blocks each re-reading the
+    // partials); ICP_NICP_FUSED=0 / 1 forces the two single-block sum+logic launches / the fused kernels
+    bool fused_enabled = g->vb == 64;
+    if (const char *e = getenv("ICP_NICP_FUSED")) fused_enabled = atoi(e) != 0;
     bool use_graph = !par.sharded() && d.n >= 1024;
     if (const char *e = getenv("ICP_NICP_GRAPH")) use_graph = !par.sharded() && atoi(e) != 0;
     if (use_graph) {
@@ -2126,10 +2287,20 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             ICP_HIP_CHECK(hipMemsetAsync(w.Ap, 0, d.np * sizeof(double), st));
             hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, -1.0, w.grad, 0.0, (const double *)nullptr, w.rcg, d.np);
             ICP_HIP_CHECK(hipMemsetAsync(w.scal, 0, sizeof(Scal), st));
-            auto precondition = [&](int init) -> int {
-                if (g->dim == 3) hipLaunchKernelGGL(cg_update_prec_kernel<3>, dim3(nbv), dim3(g->vb), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial, nown, w.st);
-                else hipLaunchKernelGGL(cg_update_prec_kernel<2>, dim3(nbv), dim3(g->vb), 0, st, (const Scal *)w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, w.partial, nown, w.st);
-                if (!par.sharded()) {
+            const double *lamd2_tail = w.lamd2 + d.n * d.S;
+            const bool fused = !par.sharded() && fused_enabled;  // see FusedCg
+            auto precondition = [&](int init, int parity) -> int {
+                const bool fz = fused && !init;
+                FusedCg fa = {w.partial, nbj, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, parity};
+                FusedCg fb = {w.partial2, nbv, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, parity};
+                double *upd_partial = fz ? w.partial2 : w.partial;
+#define NICP_UPD(D, F) hipLaunchKernelGGL((cg_update_prec_kernel<D, F>), dim3(nbv), dim3(g->vb), 0, st, w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, upd_partial, nown, w.st, (const Coarse *)w.coarse, fa)
+#define NICP_DIR(D, F) hipLaunchKernelGGL((cg_dir_prec_kernel<D, F>), dim3(nbt), dim3(g->vb), 0, st, w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown, w.st, fb)
+                if (g->dim == 3) { if (fz) NICP_UPD(3, true); else NICP_UPD(3, false); }
+                else { if (fz) NICP_UPD(2, true); else NICP_UPD(2, false); }
+                if (fz) {
+                    // sums + coarse solve happen inside the direction kernel
+                } else if (!par.sharded()) {
                     hipLaunchKernelGGL(cg_sum_coarse_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, (1u << (2 + d.NG)) - 1u,
                                        par.tot, d.NG, x_tail, r_tail, zb_tail, (const double *)p_tail, (const double *)Ap_tail, w.coarse,
                                        w.scal, init);
@@ -2139,21 +2310,24 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                     hipLaunchKernelGGL(cg_coarse_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, x_tail, r_tail, zb_tail,
                                        (const double *)p_tail, (const double *)Ap_tail, w.coarse, w.scal, init);
                 }
-                if (g->dim == 3) hipLaunchKernelGGL(cg_dir_prec_kernel<3>, dim3(nbt), dim3(g->vb), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown, w.st);
-                else hipLaunchKernelGGL(cg_dir_prec_kernel<2>, dim3(nbt), dim3(g->vb), 0, st, (const Scal *)w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown, w.st);
+                if (g->dim == 3) { if (fz) NICP_DIR(3, true); else NICP_DIR(3, false); }
+                else { if (fz) NICP_DIR(2, true); else NICP_DIR(2, false); }
+#undef NICP_UPD
+#undef NICP_DIR
                 return exchange(ctx, g, w, par, w.pcg);
             };
-            if (int rc = precondition(1)) return rc;  // alpha = 0: z = M^-1 r, rz, rr0, p = z
+            if (int rc = precondition(1, 0)) return rc;  // alpha = 0: z = M^-1 r, rz, rr0, p = z
             ICP_HIP_CHECK(hipGetLastError());
             // `count` CG iterations.  The damping enters as the vector lam*D^2 (w.lamd2, multiplier 1.0: the same
             // bits as lam * d2 * p), so no kernel argument below changes during a solve and the single-GPU
             // path can replay kCgChunk iterations as one hipGraph (6 launches each, launch-bound on small meshes).
-            const double *lamd2_tail = w.lamd2 + d.n * d.S;
             auto cg_iterations = [&](int count) -> int {
                 for (int k = 0; k < count; ++k) {
                     if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.pcg, w.y, 1)) return rc;
                     if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.y, w.lamd2, w.pcg, 1.0, w.Ap, false, false)) return rc;
-                    if (!par.sharded()) {
+                    if (fused) {
+                        // the update kernel sums the partials and derives alpha itself
+                    } else if (!par.sharded()) {
                         hipLaunchKernelGGL(cg_sum_alpha_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask | (1u << 8),
                                            par.tot, d.NG, lamd2_tail, (const double *)p_tail, 1.0, Ap_tail, w.scal);
                     } else {
@@ -2162,7 +2336,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                         hipLaunchKernelGGL(cg_alpha_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, lamd2_tail,
                                            (const double *)p_tail, 1.0, Ap_tail, w.scal);
                     }
-                    if (int rc = precondition(0)) return rc;
+                    if (int rc = precondition(0, k & 1)) return rc;
                 }
                 ICP_HIP_CHECK(hipGetLastError());
                 return ICP_OK;

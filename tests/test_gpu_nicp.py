@@ -262,6 +262,14 @@ def test_cg_graph_replay_is_bit_identical(mods, monkeypatch):
     for k in ("err", "err0", "lm_iters", "cg_iters", "nfev", "info"):
         assert out["0"][1][k] == out["1"][1][k] == out[None][1][k]
     assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][0], out[None][0])
+    # the fused update / direction kernels (default) against the separate sum+logic launches: same bits
+    monkeypatch.setenv("ICP_NICP_FUSED", "0")
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ICP_NICP_GRAPH", mode)
+        P, st = nic.solve(P0, w, v, edges, nn, C, compat=False, opts=opts)
+        assert np.array_equal(P.cpu().numpy(), out["0"][0])
+        assert all(st[k] == out["0"][1][k] for k in ("err", "err0", "lm_iters", "cg_iters", "nfev", "info"))
+    monkeypatch.delenv("ICP_NICP_FUSED")
     # small meshes stay on plain launches by default, and can be forced onto the graph
     g = golden("nicp_step_60")
     monkeypatch.delenv("ICP_NICP_GRAPH", raising=False)
