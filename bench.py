@@ -90,6 +90,10 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            # RCCL builds its communicator at the first collective (seconds): do that here, never inside the
+            # timed region, also when the caller asks for --warmup 0
+            dist.all_reduce(torch.zeros(17, dtype=torch.float64, device="cuda"))
+            torch.cuda.synchronize()
 
     from icp_amd import rigid, _lib
     from icp_amd._lib import get_context, ptr
