@@ -1577,7 +1577,7 @@ static Dims dims_of(const nicp_graph *g) {
 struct Work {
     Globals *glob;
     Scal *scal;
-    double *partial, *partial2;            // kMaxPartials * kSumSlots each (J^T kernel / CG update kernel)
+    double *partial, *partial2;            // npart * kSumSlots each (J^T kernel / CG update kernel)
     double *pre, *dd;                      // [n,dim]
     double *r, *r_trial, *y;               // nr
     double *grad, *col2, *d2, *lamd2;      // np
@@ -1596,7 +1596,9 @@ static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     const Dims d = dims_of(g);
     const size_t small = 1024;  // Globals + Scal + Coarse, in doubles (generous)
     const size_t tri = (size_t)d.S * (d.S + 1) / 2;
-    const size_t need = small + 2 * (size_t)kMaxPartials * kSumSlots + 4 * (size_t)d.n * d.dim + 4 * (size_t)d.nr + 11 * (size_t)d.np +
+    // one row of block partials per block of the per-vertex kernels: sized by the mesh, not by a fixed cap
+    const size_t npart = std::max<size_t>(kMaxPartials, (size_t)((d.n + d.NG + g->vb - 1) / g->vb) + 1);
+    const size_t need = small + 2 * npart * kSumSlots + 4 * (size_t)d.n * d.dim + 4 * (size_t)d.nr + 11 * (size_t)d.np +
                         (size_t)d.n * tri + 64;
     if (g->ws_doubles < need) {
         if (g->ws) {
@@ -1617,8 +1619,8 @@ static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     w.tot = p + 896;
     static_assert(sizeof(Globals) <= 256 * 8 && sizeof(Scal) <= 256 * 8 && sizeof(Coarse) <= 384 * 8, "small area layout");
     p += small;
-    w.partial = p; p += (size_t)kMaxPartials * kSumSlots;
-    w.partial2 = p; p += (size_t)kMaxPartials * kSumSlots;
+    w.partial = p; p += npart * kSumSlots;
+    w.partial2 = p; p += npart * kSumSlots;
     w.pre = p; p += (size_t)d.n * d.dim;
     w.dd = p; p += (size_t)d.n * d.dim;
     w.r = p; p += d.nr;
@@ -1786,10 +1788,6 @@ static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const 
     const Dims d = dims_of(g);
     const int nbk = vgrid(g, g->n);
     const double *rs = compat ? w.dd : w.pre;
-    if (nbk > kMaxPartials) {
-        set_error("nicp: mesh too large for the partial buffer (%lld vertices)", (long long)g->n);
-        return ICP_ERR_UNSUPPORTED;
-    }
     if (square) {
         NICP_DISPATCH(g->dim, compat,
                       hipLaunchKernelGGL((jtu_kernel<D, C, true>), dim3(nbk), dim3(g->vb), 0, ctx->stream, P, u, g->nbr, g->wt, g->k, v,

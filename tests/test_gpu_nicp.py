@@ -278,3 +278,27 @@ def test_cg_graph_replay_is_bit_identical(mods, monkeypatch):
     Pb, sb = nic.solve(g["P0"], g["w"], g["v"], g["edges"], g["nn"], C, compat=False)
     assert sa["graph_launches"] == 0 and sb["graph_launches"] > 0
     assert np.array_equal(Pa.cpu().numpy(), Pb.cpu().numpy())
+
+
+def test_mesh_beyond_the_old_partial_cap(mods):
+    """640 000 vertices (the block-partial buffers used to cap meshes at 2048 blocks = 524 288 vertices):
+    <Jp, Jq> == <p, J^T J q>, and a bounded solve lowers the energy, deterministically."""
+    torch = mods["torch"]
+    nic = mods["nicp"]
+    v, edges, tgt = orc.make_grid_mesh(800, 800, seed=3)
+    n = len(v)
+    w = nic.knn_weights(v)
+    P0 = nic.initial_params(n, 3)
+    rng = np.random.default_rng(1)
+    P = P0 + 0.01 * rng.standard_normal(P0.shape)
+    p, q = rng.standard_normal(P0.shape), rng.standard_normal(P0.shape)
+    Jp, Jq = nic.jvp(P, w, v, edges, C, p, compat=False), nic.jvp(P, w, v, edges, C, q, compat=False)
+    lhs = float((Jp * Jq).sum())
+    rhs = float((torch.as_tensor(p, device=Jp.device) * nic.jtvp(P, w, v, edges, C, Jq, compat=False)).sum())
+    assert abs(lhs - rhs) <= 1e-9 * abs(lhs)
+    from icp_amd import rigid
+    nn = rigid.gather_points(w.ctx.to_dev(tgt), rigid.closest_indices(v, tgt))
+    opts = dict(max_lm_iters=1, max_cg_iters=100, cg_tol=1e-6)
+    P1, st1 = nic.solve(P0, w, v, edges, nn, C, compat=False, opts=opts)
+    P2, st2 = nic.solve(P0, w, v, edges, nn, C, compat=False, opts=opts)
+    assert st1["err"] < st1["err0"] and st1 == st2 and torch.equal(P1, P2)
