@@ -1,7 +1,7 @@
 """Offline experiment (CPU, numpy, small meshes): how many preconditioned-CG iterations the NICP normal
 equations need with richer coarse spaces than the 12 global modes nicp.hip deflates today.  Uses the
-oracle's dense Jacobian, so it is a study tool, not part of the product or the tests:
-    python benchmarks/coarse_space_experiment.py 32 1e-6
+oracle's dense Jacobian, so it lives with the tests (the only place allowed to import oracle/); a study tool, not collected by pytest:
+    python tests/study_coarse_space.py 32 1e-6
 Results recorded in DESIGN.md section 7."""
 import sys, time
 sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", "oracle"))
