@@ -815,7 +815,34 @@ __global__ __launch_bounds__(NB) void scaling_kernel(const double *__restrict__ 
 // (A_j -> A_j Q, b_j -> (v_j + b_j) Q - v_j + t leaves E_rigid and E_smooth unchanged) together
 // with the explicit global parameters that duplicate them (the gauge of this model).  Without
 // it CG needs ~1e4 iterations per step at 10k vertices.
-constexpr int NZMAX = 12;
+// The coarse space can be enriched: the NG zero-stiffness modes multiplied by M low-order polynomials of the
+// (normalised) vertex position -- 1 | x y z | x^2 y^2 z^2 xy yz xz -- deflate the smooth low-frequency
+// deformations on which block-Jacobi CG spends most of its iterations (about half as many iterations with the
+// quadratics, tests/study_coarse_space.py).  Column a < NG*M of Z is phi_{a / NG}(v_j) z_{a % NG}(j); the last
+// NG columns are the global parameters.  M = 1 is the plain 2*NG-column space.
+constexpr int MAXPOLY = 10;
+constexpr int NZMAX = 6 * MAXPOLY + 6;
+constexpr int kMomSlots = 64;  // doubles per row of block moments Z_v^T r (NG*M <= 60)
+struct PolyBasis {
+    double c[3];  // centre (mean vertex)
+    double inv;   // 1 / (2 rms radius)
+    int M;        // number of polynomials in use: 1, 4, 10 (3-D) / 1, 3, 6 (2-D)
+};
+template <int DIM>
+__device__ __forceinline__ void poly_eval(const double *vj, const PolyBasis &pb, double (&phi)[MAXPOLY]) {
+    const double x = (vj[0] - pb.c[0]) * pb.inv, y = (vj[1] - pb.c[1]) * pb.inv;
+    phi[0] = 1.0;
+    if (DIM == 3) {
+        const double z = (vj[2] - pb.c[2]) * pb.inv;
+        phi[1] = x; phi[2] = y; phi[3] = z;
+        phi[4] = x * x; phi[5] = y * y; phi[6] = z * z;
+        phi[7] = x * y; phi[8] = y * z; phi[9] = x * z;
+    } else {
+        phi[1] = x; phi[2] = y;
+        phi[3] = x * x; phi[4] = y * y; phi[5] = x * y;
+        phi[6] = phi[7] = phi[8] = phi[9] = 0.0;
+    }
+}
 struct Coarse {
     double Einv[NZMAX * NZMAX];
     double E[NZMAX * NZMAX];
@@ -1003,33 +1030,74 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
 // column a of Z as a full parameter vector
 template <int DIM>
 __global__ __launch_bounds__(NB) void zcol_kernel(const double *__restrict__ P, const double *__restrict__ v, int64_t n,
-                                                 int a, double *__restrict__ out, Strides st) {
+                                                 int a, double *__restrict__ out, Strides st, PolyBasis pb) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nm = NG * pb.M, km = a % NG, mm = a / NG;
     if (j < n) {
         double z[NG][S];
-        double Pj_[S], vj_[DIM];
+        double Pj_[S], vj_[DIM], phi[MAXPOLY];
         for (int e = 0; e < S; ++e) Pj_[e] = P[j * st.pj + e * st.pe];
         for (int c = 0; c < DIM; ++c) vj_[c] = v[j * st.vj + c * st.vc];
         zmodes<DIM>(Pj_, vj_, z);
+        poly_eval<DIM>(vj_, pb, phi);
+        double f = 0.0;
+        for (int m = 0; m < MAXPOLY; ++m) f = (a < nm && m == mm) ? phi[m] : f;
         for (int e = 0; e < S; ++e) {
             double val = 0.0;
-            for (int k = 0; k < NG; ++k) val = (k == a) ? z[k][e] : val;
-            out[j * st.pj + e * st.pe] = val;
+            for (int k = 0; k < NG; ++k) val = (a < nm && k == km) ? z[k][e] : val;
+            out[j * st.pj + e * st.pe] = pb.M == 1 ? val : f * val;
         }
     } else if (j < n + NG) {
-        out[n * S + (j - n)] = (a - NG == (int)(j - n)) ? 1.0 : 0.0;
+        out[n * S + (j - n)] = (a - nm == (int)(j - n)) ? 1.0 : 0.0;
+    }
+}
+
+// Block partial of the NG*M moments  sum_j phi_m(v_j) t_k(j)  (t_k(j) = z_k(j) . r_j, zero on idle lanes) into one
+// wide row: slot m*NG + k.  One vertex per lane.  Sixty butterfly reductions would cost sixty shuffle chains, so
+// every lane parks its 10 + NG numbers in an LDS row instead and lane q < NG*M of each wave adds up "its"
+// product over the wave's 64 rows (rows are 128 B: the reads of one step fall in one row, conflict-free);
+// the waves' results are then added in wave order.  Fixed order, hence deterministic.
+template <int DIM>
+__device__ __forceinline__ void block_moments(const double (&t)[Lay<DIM>::NG], const double (&phi)[MAXPOLY], int M,
+                                              double *__restrict__ mom_row) {
+    constexpr int NG = Lay<DIM>::NG, ROW = 16;
+    static_assert(MAXPOLY + NG <= ROW, "LDS row layout");
+    __shared__ double rows[NB][ROW];
+    __shared__ double mred[NB / 64][MAXPOLY * NG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int m = 0; m < MAXPOLY; ++m) rows[tid][m] = phi[m];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) rows[tid][MAXPOLY + k] = t[k];
+    __syncthreads();
+    const int nmom = M * NG;
+    if (lane < nmom) {
+        const int m = lane / NG, k = lane % NG;
+        const double(*wr)[ROW] = rows + wave * 64;
+        double sv = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) sv += wr[i][m] * wr[i][MAXPOLY + k];
+        mred[wave][lane] = sv;
+    }
+    __syncthreads();
+    for (int q = tid; q < nmom; q += blockDim.x) {
+        double sv = mred[0][q];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) sv += mred[w][q];
+        mom_row[q] = sv;
     }
 }
 
 // partial[b][k] = sum over the block's vertices of z_k(j) . r_j  (k < NG)
 template <int DIM>
 __global__ __launch_bounds__(NB) void zt_kernel(const double *__restrict__ P, const double *__restrict__ v, int64_t n,
-                                               const double *__restrict__ r, double *__restrict__ partial, Strides st) {  // n = owned vertices
+                                               const double *__restrict__ r, double *__restrict__ partial, Strides st,
+                                               double *__restrict__ mom, PolyBasis pb) {  // n = owned vertices
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    double acc[NG];
+    double acc[NG], phi[MAXPOLY];
     for (int k = 0; k < NG; ++k) acc[k] = 0.0;
+    for (int m = 0; m < MAXPOLY; ++m) phi[m] = 0.0;
     if (j < n) {
         double z[NG][S];
         double Pj_[S], vj_[DIM];
@@ -1038,6 +1106,11 @@ __global__ __launch_bounds__(NB) void zt_kernel(const double *__restrict__ P, co
         zmodes<DIM>(Pj_, vj_, z);
         for (int k = 0; k < NG; ++k)
             for (int e = 0; e < S; ++e) acc[k] += z[k][e] * r[j * st.pj + e * st.pe];
+        if (pb.M > 1) poly_eval<DIM>(vj_, pb, phi);
+    }
+    if (pb.M > 1) {  // enriched coarse space: all NG*M moments into the wide row
+        block_moments<DIM>(acc, phi, pb.M, mom + (int64_t)blockIdx.x * kMomSlots);
+        return;
     }
     __shared__ double red[NB / 64][NG];
     const int tid = threadIdx.x;
@@ -1103,6 +1176,28 @@ __global__ __launch_bounds__(1024) void rows_sum_kernel(const double *__restrict
                                                         double *__restrict__ tot, int off) {
     block_rows_sum(partial, nb, mask, tot, off);
 }
+// tot[off + k] = sum_b mom[b][k], k < nslots, over the wide moment rows: the waves of the block share the slots
+// (1024 threads: thread = (slot, one of 16 row groups); the loads of a thread are independent and coalesced over
+// the slots, the 16 group sums meet in LDS -- no shuffle chains.)  All threads of the block must call it.
+__device__ __forceinline__ void block_rows_sum_wide(const double *__restrict__ mom, int nb, int nslots, double *__restrict__ tot,
+                                                    int off) {
+    __shared__ double wred[16][kMomSlots];
+    const int slot = threadIdx.x & (kMomSlots - 1), grp = threadIdx.x / kMomSlots, ngrp = blockDim.x / kMomSlots;
+    double a = 0.0;
+    if (slot < nslots)
+        for (int b = grp; b < nb; b += ngrp) a += mom[(int64_t)b * kMomSlots + slot];
+    wred[grp][slot] = a;
+    __syncthreads();
+    if (threadIdx.x < nslots) {
+        double sv = wred[0][threadIdx.x];
+        for (int q = 1; q < ngrp; ++q) sv += wred[q][threadIdx.x];
+        tot[off + threadIdx.x] = sv;
+    }
+}
+__global__ __launch_bounds__(1024) void rows_sum_wide_kernel(const double *__restrict__ mom, int nb, int nslots,
+                                                             double *__restrict__ tot, int off) {
+    block_rows_sum_wide(mom, nb, nslots, tot, off);
+}
 
 // out_tail[k] = tot[off + k] + lam d2_tail[k] p_tail[k]: tail of J^T u (the tail entries are replicated)
 __global__ void tail_write_kernel(const double *__restrict__ tot, int off, int ng, const double *__restrict__ d2_tail,
@@ -1111,14 +1206,14 @@ __global__ void tail_write_kernel(const double *__restrict__ tot, int off, int n
     if (k < ng) out_tail[k] = tot[off + k] + (d2_tail ? lam * d2_tail[k] * p_tail[k] : 0.0);
 }
 
-// E[:, a]: tot[0..ng) = Z_v^T w (vertex modes), tot[8..8+ng) = tail of J^T J z_a
-__global__ void ecol_logic_kernel(const double *__restrict__ tot, int ng, const double *__restrict__ d2_tail, double lam,
+// E[:, a]: tot[0..nm) = Z_v^T w (vertex modes), tot[nm+2..nm+2+ng) = tail of J^T J z_a  (nm = ng: tails at 8)
+__global__ void ecol_logic_kernel(const double *__restrict__ tot, int ng, int nm, const double *__restrict__ d2_tail, double lam,
                                   int a, Coarse *__restrict__ coarse) {
-    const int k = threadIdx.x, nz = 2 * ng;
+    const int k = threadIdx.x, nz = nm + ng;
+    if (k < nm) coarse->E[k * nz + a] = tot[k];
     if (k >= ng) return;
-    coarse->E[k * nz + a] = tot[k];
-    const double ztail = (a - ng == k) ? 1.0 : 0.0;
-    coarse->E[(ng + k) * nz + a] = tot[8 + k] + lam * d2_tail[k] * ztail;
+    const double ztail = (a - nm == k) ? 1.0 : 0.0;
+    coarse->E[(nm + k) * nz + a] = tot[nm + 2 + k] + lam * d2_tail[k] * ztail;
 }
 
 // after J^T: tail of A p, p.Ap and alpha.  tot[0..ng) tail sums, tot[8] vertex part of p.Ap  (one thread)
@@ -1151,12 +1246,12 @@ __global__ __launch_bounds__(1024) void cg_sum_alpha_kernel(const double *__rest
 }
 
 // tail update, coarse solve y = Einv Z^T r, r.z, beta, stop test.  tot[0] r.zb, tot[1] r.r, tot[2..2+ng) Z_v^T r
-__device__ __forceinline__ void coarse_logic(const double *tot, int ng, double *x_tail, double *r_tail, double *zb_tail,
+__device__ __forceinline__ void coarse_logic(const double *tot, int ng, int nm, double *x_tail, double *r_tail, double *zb_tail,
                                              const double *p_tail, const double *Ap_tail, Coarse *coarse, Scal *s, int init) {
     const int tid = threadIdx.x;
     const int stop = s->stop;  // uniform: only thread 0 writes it, at the very end
     if (stop) return;
-    const int nz = 2 * ng;
+    const int nz = nm + ng;  // tot[2..2+nm) Z_v^T r  (nm = ng for the plain coarse space)
     __shared__ double ztr_s[NZMAX], y_s[NZMAX], acc_s[2];
     if (tid == 0) {
         double rz = tot[0], rr = tot[1];
@@ -1169,24 +1264,55 @@ __device__ __forceinline__ void coarse_logic(const double *tot, int ng, double *
             zb_tail[k] = zt;
             rz += rt * zt;
             rr += rt * rt;
-            ztr_s[k] = tot[2 + k];
-            ztr_s[ng + k] = rt;
+            ztr_s[nm + k] = rt;
         }
         acc_s[0] = rz;
         acc_s[1] = rr;
     }
+    for (int k = tid; k < nm; k += blockDim.x) ztr_s[k] = tot[2 + k];
     __syncthreads();
-    if (tid < nz) {  // y = Einv Z^T r, one row per thread
-        double y = 0.0;
-        for (int b = 0; b < nz; ++b) y += coarse->Einv[tid * nz + b] * ztr_s[b];
-        y_s[tid] = y;
-        coarse->y[tid] = y;
+    // y = Einv Z^T r.  Einv is exactly symmetric (the host symmetrises it): column `row` read as a row is coalesced
+    // over the threads.
+    if (nz > 16 && blockDim.x >= 256) {
+        // enriched space in a large block: thread = (row, one of blockDim/128 column chunks), every load independent
+        __shared__ double ypart[8][NZMAX];
+        const int row = tid & 127, chunk = tid >> 7, nch = blockDim.x >> 7, per = (nz + nch - 1) / nch;
+        if (row < nz) {
+            double y = 0.0;
+            const int b1 = (chunk + 1) * per < nz ? (chunk + 1) * per : nz;
+            for (int b = chunk * per; b < b1; ++b) y += coarse->Einv[b * nz + row] * ztr_s[b];
+            ypart[chunk][row] = y;
+        }
+        __syncthreads();
+        if (tid < nz) {
+            double y = ypart[0][tid];
+            for (int q = 1; q < nch; ++q) y += ypart[q][tid];
+            y_s[tid] = y;
+            coarse->y[tid] = y;
+        }
+    } else {
+        for (int row = tid; row < nz; row += blockDim.x) {  // one row per thread, columns in order
+            double y = 0.0;
+            for (int b = 0; b < nz; ++b) y += coarse->Einv[b * nz + row] * ztr_s[b];
+            y_s[row] = y;
+            coarse->y[row] = y;
+        }
     }
     __syncthreads();
+    double zy = 0.0;  // (Z^T r) . y, complete on thread 0
+    if (nz > 16) {    // enriched space: the first wave adds the up to 128 products
+        if (tid < 64) {
+            zy = tid < nz ? ztr_s[tid] * y_s[tid] : 0.0;
+            if (tid + 64 < nz) zy += ztr_s[tid + 64] * y_s[tid + 64];
+            zy = wave_sum(zy);
+        }
+    }
     if (tid != 0) return;
     double rz = acc_s[0];
     const double rr = acc_s[1];
-    for (int a = 0; a < nz; ++a) rz += ztr_s[a] * y_s[a];
+    if (nz > 16) rz += zy;
+    else
+        for (int a = 0; a < nz; ++a) rz += ztr_s[a] * y_s[a];  // the plain space keeps its historical order (= the fused kernels')
     s->rz_new = rz;
     s->rr = rr;
     if (init) {
@@ -1201,20 +1327,26 @@ __device__ __forceinline__ void coarse_logic(const double *tot, int ng, double *
         if (!(rr > coarse->tol2 * s->rr0)) s->stop = 1;
     }
 }
-__global__ __launch_bounds__(64) void cg_coarse_logic_kernel(const double *__restrict__ tot, int ng, double *__restrict__ x_tail,
+__global__ __launch_bounds__(128) void cg_coarse_logic_kernel(const double *__restrict__ tot, int ng, double *__restrict__ x_tail,
                                                             double *__restrict__ r_tail, double *__restrict__ zb_tail,
                                                             const double *__restrict__ p_tail, const double *__restrict__ Ap_tail,
-                                                            Coarse *__restrict__ coarse, Scal *__restrict__ s, int init) {
-    coarse_logic(tot, ng, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s, init);
+                                                            Coarse *__restrict__ coarse, Scal *__restrict__ s, int init, int nm) {
+    coarse_logic(tot, ng, nm, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s, init);
 }
+// mom != null (enriched coarse space): the moments come from the wide rows, slots 0/1 (r.zb, r.r) from `partial`
 __global__ __launch_bounds__(1024) void cg_sum_coarse_kernel(const double *__restrict__ partial, int nb, unsigned mask,
                                                              double *__restrict__ tot, int ng, double *__restrict__ x_tail,
                                                              double *__restrict__ r_tail, double *__restrict__ zb_tail,
                                                              const double *__restrict__ p_tail, const double *__restrict__ Ap_tail,
-                                                             Coarse *__restrict__ coarse, Scal *__restrict__ s, int init) {
-    block_rows_sum(partial, nb, mask, tot, 0);
+                                                             Coarse *__restrict__ coarse, Scal *__restrict__ s, int init,
+                                                             const double *__restrict__ mom, int nm) {
+    // the sums stay in LDS (no round trip through `tot`, which nothing else reads on the single-GPU path)
+    __shared__ double tot_s[2 + kMomSlots];
+    (void)tot;
+    block_rows_sum(partial, nb, mask, tot_s, 0);
+    if (mom) block_rows_sum_wide(mom, nb, nm, tot_s, 2);
     __syncthreads();
-    coarse_logic(tot, ng, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s, init);
+    coarse_logic(tot_s, ng, nm, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s, init);
 }
 
 // tot[slot] += sum_k a[k] b[k] (w ? w[k] : 1) over the ng replicated tail entries (added on one rank only)
@@ -1288,11 +1420,13 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
                                                            double *__restrict__ zb, const double *__restrict__ p,
                                                            const double *__restrict__ Ap, const double *__restrict__ binv,
                                                            double *__restrict__ partial, int64_t nown, Strides st,
-                                                           const Coarse *__restrict__ coarse, FusedCg f) {
+                                                           const Coarse *__restrict__ coarse, FusedCg f,
+                                                           double *__restrict__ mom, PolyBasis pb) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    double acc[2 + NG];
+    double acc[2 + NG], phi[MAXPOLY];
     for (int k = 0; k < 2 + NG; ++k) acc[k] = 0.0;
+    for (int m = 0; m < MAXPOLY; ++m) phi[m] = 0.0;
     double alpha_blk = 0.0;
     bool stop_blk;
     if constexpr (FUSED) {
@@ -1371,6 +1505,7 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
             }
         double z[NG][S];
         zmodes<DIM>(Pj_, vj_, z);
+        if (!FUSED && pb.M > 1) poly_eval<DIM>(vj_, pb, phi);
 #pragma unroll
         for (int e = 0; e < S; ++e) {
             acc[0] += rj[e] * zj[e];
@@ -1398,6 +1533,12 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t += red[w][tid];
         partial[(int64_t)blockIdx.x * kSumSlots + tid] = t;
     }
+    if (!FUSED && pb.M > 1) {  // enriched coarse space: the NG*M moments of the new residual
+        double tk[NG];
+#pragma unroll
+        for (int k = 0; k < NG; ++k) tk[k] = acc[2 + k];
+        block_moments<DIM>(tk, phi, pb.M, mom + (int64_t)blockIdx.x * kMomSlots);
+    }
 }
 
 // z = zb + Z y; p = z + beta p
@@ -1405,8 +1546,9 @@ template <int DIM, bool FUSED>
 __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, const Coarse *__restrict__ coarse,
                                                         const double *__restrict__ P, const double *__restrict__ v, int64_t n,
                                                         const double *__restrict__ zb, double *__restrict__ p, int64_t nown,
-                                                        Strides st, FusedCg f) {
+                                                        Strides st, FusedCg f, PolyBasis pb) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
+    const int nm = FUSED ? NG : NG * pb.M;  // vertex-mode columns of Z (the fused kernels serve the plain space only)
     __shared__ double y_s[NZMAX];
     double beta;
     if constexpr (FUSED) {
@@ -1463,7 +1605,7 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, c
     } else {
         if (s->stop) return;
         beta = s->beta;
-        if (threadIdx.x < 2 * NG) y_s[threadIdx.x] = coarse->y[threadIdx.x];
+        for (int i = threadIdx.x; i < nm + NG; i += blockDim.x) y_s[i] = coarse->y[i];
         __syncthreads();
     }
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1481,6 +1623,17 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, c
         for (int c = 0; c < DIM; ++c) vj_[c] = v[j * st.vj + c * st.vc];
 #pragma unroll
         for (int k = 0; k < NG; ++k) yk[k] = y_s[k];
+        if (!FUSED && pb.M > 1) {  // y_k(j) = sum_m y[m*NG + k] phi_m(v_j)
+            double phi[MAXPOLY];
+            poly_eval<DIM>(vj_, pb, phi);
+#pragma unroll
+            for (int m = 1; m < MAXPOLY; ++m) {
+                if (m < pb.M) {  // uniform
+#pragma unroll
+                    for (int k = 0; k < NG; ++k) yk[k] += y_s[m * NG + k] * phi[m];
+                }
+            }
+        }
         zmodes<DIM>(Pj_, vj_, z);
 #pragma unroll
         for (int e = 0; e < S; ++e) {
@@ -1493,7 +1646,7 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, c
         for (int e = 0; e < S; ++e) p[j * st.pj + e * st.pe] = pj[e];
     } else if (j < n + NG) {
         const int k = (int)(j - n);
-        p[n * S + k] = zb[n * S + k] + y_s[NG + k] + beta * p[n * S + k];
+        p[n * S + k] = zb[n * S + k] + y_s[nm + k] + beta * p[n * S + k];
     }
 }
 
@@ -1550,6 +1703,33 @@ __global__ __launch_bounds__(NB) void landmark_map_kernel(const int32_t *__restr
     if (atomicCAS(&lm_of[vtx], -1, (int32_t)k) != -1) atomicAdd(&err[1], 1);
 }
 
+// partial[b][0..dim) = sum (v_j - c), [3] = sum |v_j - c|^2, [4] = count, over the owned vertices
+__global__ __launch_bounds__(NB) void vstats_kernel(const double *__restrict__ v, int64_t nown, int dim, Strides st, double c0, double c1,
+                                                   double c2, double *__restrict__ partial) {
+    double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    const double c[3] = {c0, c1, c2};
+    for (int64_t j = (int64_t)blockIdx.x * NB + threadIdx.x; j < nown; j += (int64_t)gridDim.x * NB) {
+        for (int k = 0; k < dim; ++k) {
+            const double x = v[j * st.vj + k * st.vc] - c[k];
+            a[k] += x;
+            a[3] += x * x;
+        }
+        a[4] += 1.0;
+    }
+    __shared__ double red[NB / 64][5];
+    const int tid = threadIdx.x;
+    for (int k = 0; k < 5; ++k) {
+        const double sv = wave_sum(a[k]);
+        if ((tid & 63) == 0) red[tid >> 6][k] = sv;
+    }
+    __syncthreads();
+    if (tid < 5) {
+        double sv = red[0][tid];
+        for (int w = 1; w < NB / 64; ++w) sv += red[w][tid];
+        partial[(int64_t)blockIdx.x * kSumSlots + tid] = sv;
+    }
+}
+
 static inline int vgrid(const nicp_graph *g, int64_t len) { return (int)((len + g->vb - 1) / g->vb); }
 static inline int grid_for(int64_t len, int cap = 1024) {
     int64_t nb = (len + NB - 1) / NB;
@@ -1578,6 +1758,8 @@ struct Work {
     Globals *glob;
     Scal *scal;
     double *partial, *partial2;            // npart * kSumSlots each (J^T kernel / CG update kernel)
+    double *mom;                           // npart * kMomSlots: block moments Z_v^T r of the enriched coarse space
+    PolyBasis pb;                          // coarse-space polynomials of this solve (M = 1: plain space)
     double *pre, *dd;                      // [n,dim]
     double *r, *r_trial, *y;               // nr
     double *grad, *col2, *d2, *lamd2;      // np
@@ -1594,11 +1776,12 @@ struct Work {
 
 static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     const Dims d = dims_of(g);
-    const size_t small = 1024;  // Globals + Scal + Coarse, in doubles (generous)
+    constexpr size_t coarse_doubles = (sizeof(Coarse) + 7) / 8;
+    const size_t small = 1024 + coarse_doubles;  // Globals | Scal | tot (128) | Coarse, in doubles
     const size_t tri = (size_t)d.S * (d.S + 1) / 2;
     // one row of block partials per block of the per-vertex kernels: sized by the mesh, not by a fixed cap
     const size_t npart = std::max<size_t>(kMaxPartials, (size_t)((d.n + d.NG + g->vb - 1) / g->vb) + 1);
-    const size_t need = small + 2 * npart * kSumSlots + 4 * (size_t)d.n * d.dim + 4 * (size_t)d.nr + 11 * (size_t)d.np +
+    const size_t need = small + 2 * npart * kSumSlots + npart * kMomSlots + 4 * (size_t)d.n * d.dim + 4 * (size_t)d.nr + 11 * (size_t)d.np +
                         (size_t)d.n * tri + 64;
     if (g->ws_doubles < need) {
         if (g->ws) {
@@ -1615,12 +1798,13 @@ static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     double *p = g->ws;
     w.glob = (Globals *)p;
     w.scal = (Scal *)(p + 256);
-    w.coarse = (Coarse *)(p + 512);
-    w.tot = p + 896;
-    static_assert(sizeof(Globals) <= 256 * 8 && sizeof(Scal) <= 256 * 8 && sizeof(Coarse) <= 384 * 8, "small area layout");
+    w.tot = p + 512;
+    w.coarse = (Coarse *)(p + 1024);
+    static_assert(sizeof(Globals) <= 256 * 8 && sizeof(Scal) <= 256 * 8, "small area layout");
     p += small;
     w.partial = p; p += npart * kSumSlots;
     w.partial2 = p; p += npart * kSumSlots;
+    w.mom = p; p += npart * kMomSlots;
     w.pre = p; p += (size_t)d.n * d.dim;
     w.dd = p; p += (size_t)d.n * d.dim;
     w.r = p; p += d.nr;
@@ -1637,6 +1821,7 @@ static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     w.nns = p; p += (size_t)d.n * d.dim;
     w.masks = p;
     w.st = d.dim == 3 ? strides_aos<3>() : strides_aos<2>();
+    w.pb = PolyBasis{{0.0, 0.0, 0.0}, 1.0, 1};
     w.rw = RowW();
     w.rw.fit = g->fw;
     w.rw.rig = g->gw;
@@ -1867,6 +2052,59 @@ static bool invert_spd(const double *E, int nz, double *out) {
     for (int i = 0; i < nz; ++i)
         for (int j = 0; j < nz; ++j) out[i * nz + j] = 0.5 * (a[i][nz + j] + a[j][nz + i]);
     return true;
+}
+
+// Inverse of the coarse matrix on its numerically independent columns.  The enriched coarse space can be rank
+// deficient -- on a sphere x^2 + y^2 + z^2 is constant, the global parameters duplicate the constant modes -- so
+// columns are picked by pivoted Cholesky on the unit-diagonal scaling of E until the residual diagonal falls below
+// `tol`, E is inverted on that set and the rows / columns of the dropped modes are zero: Z Einv Z^T stays symmetric
+// positive semi-definite, which is all the preconditioner needs.  Returns the number of columns kept.
+static int invert_spd_rank_revealing(const double *E, int nz, double *out, double tol = 1e-9) {
+    std::vector<double> A((size_t)nz * nz), L((size_t)nz * nz, 0.0), dres(nz), sc(nz);
+    for (int i = 0; i < nz; ++i) {
+        const double dgi = E[i * nz + i];
+        sc[i] = (dgi > 0.0 && std::isfinite(dgi)) ? 1.0 / std::sqrt(dgi) : 0.0;
+    }
+    for (int i = 0; i < nz; ++i)
+        for (int j = 0; j < nz; ++j) {
+            const double val = 0.5 * (E[i * nz + j] + E[j * nz + i]) * sc[i] * sc[j];
+            if (!std::isfinite(val)) {
+                std::fill(out, out + (size_t)nz * nz, 0.0);
+                return 0;
+            }
+            A[(size_t)i * nz + j] = val;
+        }
+    for (int i = 0; i < nz; ++i) dres[i] = A[(size_t)i * nz + i];  // 1 (or 0 for a dead column)
+    std::vector<int> kept;
+    std::vector<char> used(nz, 0);
+    for (int step = 0; step < nz; ++step) {
+        int piv = -1;
+        for (int i = 0; i < nz; ++i)
+            if (!used[i] && (piv < 0 || dres[i] > dres[piv])) piv = i;
+        if (piv < 0 || !(dres[piv] > tol)) break;
+        used[piv] = 1;
+        const int kcol = (int)kept.size();
+        kept.push_back(piv);
+        const double root = std::sqrt(dres[piv]);
+        for (int i = 0; i < nz; ++i) {
+            if (used[i] && i != piv) continue;
+            double val = A[(size_t)i * nz + piv];
+            for (int j = 0; j < kcol; ++j) val -= L[(size_t)i * nz + j] * L[(size_t)piv * nz + j];
+            L[(size_t)i * nz + kcol] = val / root;
+        }
+        for (int i = 0; i < nz; ++i)
+            if (!used[i]) dres[i] -= L[(size_t)i * nz + kcol] * L[(size_t)i * nz + kcol];
+    }
+    std::fill(out, out + (size_t)nz * nz, 0.0);
+    const int nk = (int)kept.size();
+    if (nk == 0) return 0;
+    std::vector<double> Ek((size_t)nk * nk), Eki((size_t)nk * nk);
+    for (int a = 0; a < nk; ++a)
+        for (int b = 0; b < nk; ++b) Ek[(size_t)a * nk + b] = A[(size_t)kept[a] * nz + kept[b]];
+    if (!invert_spd(Ek.data(), nk, Eki.data())) return 0;
+    for (int a = 0; a < nk; ++a)
+        for (int b = 0; b < nk; ++b) out[(size_t)kept[a] * nz + kept[b]] = Eki[(size_t)a * nk + b] * (sc[kept[a]] * sc[kept[b]]);  // exactly symmetric
+    return nk;
 }
 
 static int read_scal(icp_ctx *ctx, const Scal *dev, Scal &host) {
@@ -2167,6 +2405,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
     nicp_solve_stats stt = {0, 0, 0, 0, 0, 0, 0};
     const int nbp = grid_for(d.np);
     const int64_t nown = par_in.nown;
+    int coarse_switch_to = 1;  // coarse-space size to move to once CG gets long (see below)
 
     // ---- solver-internal, lane-transposed copies of the inputs (see Strides)
     if (int rc = refuse_compat_weights(w, compat)) return rc;
@@ -2189,6 +2428,36 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
     w.st = soa;
     double *x = w.xs;
     const double *v = w.vs, *nn = w.nns;
+    // ---- coarse-space polynomials: centre and radius of the (whole) mesh from all-reduced sums, so every rank of
+    // a sharded solve builds the same basis.  Default (meshes of >= 2048 vertices): start with the plain space and
+    // switch to the quadratics for the rest of the solve once a linear solve has needed more than 400 CG iterations
+    // (the 54 extra columns of E cost about 75 iterations' worth of launches per LM step and repay from ~200 on);
+    // ICP_NICP_COARSE = 1 | 4 | 10 (3-D) / 1 | 3 | 6 (2-D) fixes the space instead.
+    {
+        const int nbs = grid_for(nown);
+        double cen[3] = {0.0, 0.0, 0.0}, hv[5];
+        for (int pass = 0; pass < 2; ++pass) {
+            hipLaunchKernelGGL(vstats_kernel, dim3(nbs), dim3(NB), 0, st, v, nown, d.dim, w.st, cen[0], cen[1], cen[2], w.partial);
+            hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbs, 0x1fu, par.tot, 0);
+            if (int rc = allreduce(par, 5)) return rc;
+            if (int rc = read_tot(ctx, par, 5, hv)) return rc;
+            if (pass == 0 && hv[4] > 0)
+                for (int k = 0; k < d.dim; ++k) cen[k] = hv[k] / hv[4];
+        }
+        const double rms = hv[4] > 0 ? std::sqrt(hv[3] / hv[4]) : 0.0;
+        PolyBasis pb = {{cen[0], cen[1], cen[2]}, (rms > 0.0 && std::isfinite(rms)) ? 0.5 / rms : 1.0, 1};
+        const int mmax = d.dim == 3 ? 10 : 6, mlin = d.dim == 3 ? 4 : 3;
+        int M = 1;
+        coarse_switch_to = hv[4] >= 2048.0 ? mmax : 1;
+        if (const char *e = getenv("ICP_NICP_COARSE")) {
+            const int want = atoi(e);
+            M = want >= mmax ? mmax : (want >= mlin ? mlin : 1);
+            coarse_switch_to = M;
+        }
+        if (!std::isfinite(cen[0] + cen[1] + cen[2])) M = coarse_switch_to = 1;
+        pb.M = M;
+        w.pb = pb;
+    }
     if (int rc = residual_at(ctx, g, w, x, v, nn, c, compat, w.r)) return rc;
     if (int rc = dot_slot(ctx, w, par, w.r, w.r, par.row_mask, d.nr, 0)) return rc;
     if (int rc = allreduce(par, 1)) return rc;
@@ -2204,6 +2473,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
     struct CgGraph {
         hipGraphExec_t exec = nullptr;
         bool failed = false;
+        int M = 0;
         ~CgGraph() {
             if (exec) (void)hipGraphExecDestroy(exec);
         }
@@ -2243,7 +2513,9 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             hipLaunchKernelGGL(scaling_kernel, dim3(nbp), dim3(NB), 0, st, w.col2, w.d2, w.lamd2, lam, first_scaling ? 1 : 0, d.np);
             first_scaling = false;
             // ---- two-level preconditioner for (J^T J + lam D^2): inverted vertex blocks + coarse space
-            const int nbv = vgrid(g, nown), nbt = vgrid(g, d.n + d.NG), nz = 2 * d.NG;
+            const int nm = d.NG * w.pb.M;  // vertex-mode columns of Z in this linear solve
+            const int nbv = vgrid(g, nown), nbt = vgrid(g, d.n + d.NG), nz = nm + d.NG;
+            const bool rich = w.pb.M > 1;
             const int nbj = vgrid(g, d.n);  // blocks of the J^T kernel (all local vertices)
             const unsigned ng_mask = (1u << d.NG) - 1u;
             double *x_tail = w.delta + d.n * d.S, *r_tail = w.rcg + d.n * d.S, *zb_tail = w.z + d.n * d.S;
@@ -2257,23 +2529,28 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                                              w.binv, w.coarse, w.st, w.rw));
             ICP_HIP_CHECK(hipGetLastError());
             for (int a = 0; a < nz; ++a) {  // E[:, a] = Z^T (J^T J + lam D^2) z_a
-                if (g->dim == 3) hipLaunchKernelGGL(zcol_kernel<3>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z, w.st);
-                else hipLaunchKernelGGL(zcol_kernel<2>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z, w.st);
+                if (g->dim == 3) hipLaunchKernelGGL(zcol_kernel<3>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z, w.st, w.pb);
+                else hipLaunchKernelGGL(zcol_kernel<2>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z, w.st, w.pb);
                 if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.z, w.y, 1)) return rc;
                 if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.y, w.d2, w.z, lam, w.Ap, false, false)) return rc;
-                hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask, par.tot, 8);
-                if (g->dim == 3) hipLaunchKernelGGL(zt_kernel<3>, dim3(nbv), dim3(g->vb), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial, w.st);
-                else hipLaunchKernelGGL(zt_kernel<2>, dim3(nbv), dim3(g->vb), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial, w.st);
-                hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, ng_mask, par.tot, 0);
-                if (int rc = allreduce(par, 16)) return rc;
-                hipLaunchKernelGGL(ecol_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, d2_tail, lam, a, w.coarse);
+                hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask, par.tot, nm + 2);
+                if (g->dim == 3) hipLaunchKernelGGL(zt_kernel<3>, dim3(nbv), dim3(g->vb), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial, w.st, w.mom, w.pb);
+                else hipLaunchKernelGGL(zt_kernel<2>, dim3(nbv), dim3(g->vb), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial, w.st, w.mom, w.pb);
+                if (rich) hipLaunchKernelGGL(rows_sum_wide_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.mom, nbv, nm, par.tot, 0);
+                else hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, ng_mask, par.tot, 0);
+                if (int rc = allreduce(par, std::max(16, nm + 2 + d.NG))) return rc;
+                hipLaunchKernelGGL(ecol_logic_kernel, dim3(1), dim3(128), 0, st, (const double *)par.tot, d.NG, nm, d2_tail, lam, a, w.coarse);
             }
             ICP_HIP_CHECK(hipGetLastError());
             {
                 double E[NZMAX * NZMAX], Einv[NZMAX * NZMAX];
                 ICP_HIP_CHECK(hipMemcpyAsync(E, w.coarse->E, sizeof(double) * nz * nz, hipMemcpyDeviceToHost, st));
                 ICP_HIP_CHECK(hipStreamSynchronize(st));
-                if (!invert_spd(E, nz, Einv)) std::memset(Einv, 0, sizeof(Einv));  // fall back to the block level alone
+                if (rich) {
+                    (void)invert_spd_rank_revealing(E, nz, Einv);  // dependent modes dropped; all dropped: block level alone
+                } else if (!invert_spd(E, nz, Einv)) {
+                    std::memset(Einv, 0, sizeof(Einv));  // fall back to the block level alone
+                }
                 ICP_HIP_CHECK(hipMemcpyAsync(w.coarse->Einv, Einv, sizeof(double) * nz * nz, hipMemcpyHostToDevice, st));
                 const double tol2 = cg_tol_now * cg_tol_now;
                 ICP_HIP_CHECK(hipMemcpyAsync(&w.coarse->tol2, &tol2, sizeof(double), hipMemcpyHostToDevice, st));
@@ -2286,27 +2563,30 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, -1.0, w.grad, 0.0, (const double *)nullptr, w.rcg, d.np);
             ICP_HIP_CHECK(hipMemsetAsync(w.scal, 0, sizeof(Scal), st));
             const double *lamd2_tail = w.lamd2 + d.n * d.S;
-            const bool fused = !par.sharded() && fused_enabled;  // see FusedCg
+            const bool fused = !par.sharded() && fused_enabled && !rich;  // see FusedCg (plain coarse space only)
+            // slots of the update kernel's partial rows that the sums read: r.zb, r.r (+ the NG plain moments)
+            const unsigned upd_mask = rich ? 0x3u : (1u << (2 + d.NG)) - 1u;
             auto precondition = [&](int init, int parity) -> int {
                 const bool fz = fused && !init;
                 FusedCg fa = {w.partial, nbj, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, parity};
                 FusedCg fb = {w.partial2, nbv, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, parity};
                 double *upd_partial = fz ? w.partial2 : w.partial;
-#define NICP_UPD(D, F) hipLaunchKernelGGL((cg_update_prec_kernel<D, F>), dim3(nbv), dim3(g->vb), 0, st, w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, upd_partial, nown, w.st, (const Coarse *)w.coarse, fa)
-#define NICP_DIR(D, F) hipLaunchKernelGGL((cg_dir_prec_kernel<D, F>), dim3(nbt), dim3(g->vb), 0, st, w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown, w.st, fb)
+#define NICP_UPD(D, F) hipLaunchKernelGGL((cg_update_prec_kernel<D, F>), dim3(nbv), dim3(g->vb), 0, st, w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, upd_partial, nown, w.st, (const Coarse *)w.coarse, fa, w.mom, w.pb)
+#define NICP_DIR(D, F) hipLaunchKernelGGL((cg_dir_prec_kernel<D, F>), dim3(nbt), dim3(g->vb), 0, st, w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown, w.st, fb, w.pb)
                 if (g->dim == 3) { if (fz) NICP_UPD(3, true); else NICP_UPD(3, false); }
                 else { if (fz) NICP_UPD(2, true); else NICP_UPD(2, false); }
                 if (fz) {
                     // sums + coarse solve happen inside the direction kernel
                 } else if (!par.sharded()) {
-                    hipLaunchKernelGGL(cg_sum_coarse_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, (1u << (2 + d.NG)) - 1u,
+                    hipLaunchKernelGGL(cg_sum_coarse_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, upd_mask,
                                        par.tot, d.NG, x_tail, r_tail, zb_tail, (const double *)p_tail, (const double *)Ap_tail, w.coarse,
-                                       w.scal, init);
+                                       w.scal, init, (const double *)(rich ? w.mom : nullptr), nm);
                 } else {
-                    hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, (1u << (2 + d.NG)) - 1u, par.tot, 0);
-                    if (int rc = allreduce(par, 2 + d.NG)) return rc;
-                    hipLaunchKernelGGL(cg_coarse_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, x_tail, r_tail, zb_tail,
-                                       (const double *)p_tail, (const double *)Ap_tail, w.coarse, w.scal, init);
+                    hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, upd_mask, par.tot, 0);
+                    if (rich) hipLaunchKernelGGL(rows_sum_wide_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.mom, nbv, nm, par.tot, 2);
+                    if (int rc = allreduce(par, 2 + nm)) return rc;
+                    hipLaunchKernelGGL(cg_coarse_logic_kernel, dim3(1), dim3(128), 0, st, (const double *)par.tot, d.NG, x_tail, r_tail, zb_tail,
+                                       (const double *)p_tail, (const double *)Ap_tail, w.coarse, w.scal, init, nm);
                 }
                 if (g->dim == 3) { if (fz) NICP_DIR(3, true); else NICP_DIR(3, false); }
                 else { if (fz) NICP_DIR(2, true); else NICP_DIR(2, false); }
@@ -2339,6 +2619,11 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 ICP_HIP_CHECK(hipGetLastError());
                 return ICP_OK;
             };
+            if (cg.exec && cg.M != w.pb.M) {  // the coarse space changed: the captured launches no longer apply
+                (void)hipGraphExecDestroy(cg.exec);
+                cg.exec = nullptr;
+            }
+            cg.M = w.pb.M;
             if (use_graph && !cg.exec && !cg.failed) {
                 // capture once per solve, on the context's side stream (st may be the legacy default stream)
                 hipStream_t user = ctx->stream;
@@ -2378,6 +2663,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 cg_done = hs.stop;
             }
             stt.cg_iters += hs.iters;
+            if (hs.iters > 400 && w.pb.M < coarse_switch_to) w.pb.M = coarse_switch_to;  // same decision on every rank (global counters)
             if (int rc = exchange(ctx, g, w, par, w.delta)) return rc;
             // ---- trial point and gain ratio
             hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, 1.0, (const double *)x, 1.0, (const double *)w.delta, w.x_trial, d.np);

@@ -191,7 +191,7 @@ class TorchComm:
         S = shard.dim * shard.dim + shard.dim
         self.S = S
         f64 = torch.float64
-        self.reduce_buf = torch.zeros(64, dtype=f64, device=device)
+        self.reduce_buf = torch.zeros(128, dtype=f64, device=device)
         self.send_idx = torch.from_numpy(shard.send_idx.astype(np.int32)).to(device)
         self.send_buf = torch.zeros(max(len(shard.send_idx), 1) * S, dtype=f64, device=device)
         self.recv_buf = torch.zeros(max(shard.n_halo, 1) * S, dtype=f64, device=device)

@@ -235,8 +235,10 @@ typedef struct nicp_solve_stats {
 /* The optimize.leastsq call of nicp_3d.py:351 / nicp_row.py:246: minimise |MinFunc(P)|^2 from
  * P_inout with correspondences nn fixed.  Levenberg-Marquardt; each step solves
  * (J^T J + lambda D^2) delta = -J^T r by conjugate gradients on the matrix-free operators above,
- * preconditioned by the inverted per-vertex blocks plus a 12-dimensional (6 in 2-D) coarse space
- * of the modes the stiffness terms cannot see.  On one GPU the CG iterations are replayed 50 at a time
+ * preconditioned by the inverted per-vertex blocks plus a coarse space of the modes the stiffness
+ * terms cannot see: 12 columns (6 in 2-D), enriched to 66 (21) -- those modes times the quadratic
+ * polynomials of the vertex position -- on meshes of >= 2048 vertices once a linear solve needs more
+ * than 400 iterations (environment ICP_NICP_COARSE = 1 | 4 | 10 fixes the space).  On one GPU the CG iterations are replayed 50 at a time
  * as a hipGraph captured once per solve (meshes of >= 1024 vertices; environment ICP_NICP_GRAPH=0/1
  * forces it off/on; same kernels, same bits).  opts_host may be NULL; stats_host may be NULL.  Synchronises. */
 int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, const double *nn,
@@ -254,7 +256,7 @@ int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, co
 typedef struct nicp_comm {
     int rank, world;
     int64_t n_owned;             /* the first n_owned local vertices are owned, the rest are halo copies */
-    double *reduce_buf_dev;      /* >= 64 doubles; allreduce_sum sums its first `count` entries over ranks in place */
+    double *reduce_buf_dev;      /* >= 128 doubles; allreduce_sum sums its first `count` entries over ranks in place */
     const int32_t *send_idx_dev; /* [n_send] local ids of owned vertices that peers hold as halo, grouped by destination rank */
     int64_t n_send;
     double *send_buf_dev;        /* [n_send, S] packed by the library before every exchange, S = dim*dim+dim */
@@ -266,7 +268,7 @@ typedef struct nicp_comm {
 } nicp_comm;
 
 /* nicp_solve on one rank of a sharded mesh: same algorithm, every sum completed by allreduce_sum
- * (<= 16 doubles each) and the search direction's halo refreshed once per CG iteration.  g is the
+ * (<= 68 doubles each) and the search direction's halo refreshed once per CG iteration.  g is the
  * LOCAL graph, P_inout the local parameter vector [owned | halo | tail] (tail replicated), nn the
  * matched points of the local vertices.  stats are global.  flags must be 0: quirk Q5 of the
  * compat mode couples rigid-residual slots of unrelated vertices and does not shard.  Every rank

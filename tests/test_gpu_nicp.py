@@ -302,3 +302,32 @@ def test_mesh_beyond_the_old_partial_cap(mods):
     P1, st1 = nic.solve(P0, w, v, edges, nn, C, compat=False, opts=opts)
     P2, st2 = nic.solve(P0, w, v, edges, nn, C, compat=False, opts=opts)
     assert st1["err"] < st1["err0"] and st1 == st2 and torch.equal(P1, P2)
+
+
+@pytest.mark.parametrize("name,coarse", [("nicp_step_60", "10"), ("nicp_step_60", "4"), ("nicp_step_24", "10"), ("nicp_row_20", "6"),
+                                         ("nicp_row_20", "3")])
+def test_enriched_coarse_space_same_minimiser(mods, monkeypatch, name, coarse):
+    """The polynomial-enriched coarse space only changes the preconditioner: the solve must land on the same
+    minimiser (scipy's leastsq on the oracle's consistent pair) to 1e-6, here forced onto small meshes."""
+    from scipy import optimize
+    g = golden(name)
+    v, edges, nn, P0 = g["v"], g["edges"], g["nn"], g["P0"]
+    dim = v.shape[1]
+    nbr, wt = sparse_from_dense(g["w"])
+    lsq = optimize.leastsq(lambda p: orc.min_func(p, nbr, wt, v, edges, nn, C, False), P0,
+                           Dfun=lambda p: orc.d_min_func(p, nbr, wt, v, edges, nn, C, False), full_output=1,
+                           ftol=1e-13, xtol=1e-13)          # all three solvers run to the minimiser itself
+    dd_ref = orc.deform(lsq[0], nbr, wt, v)
+    nic = mods["nicp"]
+    w = nic.SparseWeights(nbr, wt, dim)
+    tight = dict(ftol=1e-13, xtol=1e-13)
+    monkeypatch.setenv("ICP_NICP_COARSE", "1")
+    P1, st1 = nic.solve(P0, w, v, edges, nn, C, compat=False, opts=tight)
+    monkeypatch.setenv("ICP_NICP_COARSE", coarse)
+    P2, st2 = nic.solve(P0, w, v, edges, nn, C, compat=False, opts=tight)
+    print(name, coarse, "plain", st1, "enriched", st2)
+    np.testing.assert_allclose(st2["err"], (lsq[2]["fvec"] ** 2).sum(), rtol=1e-6)
+    # 1e-6 relative; the absolute floor is 1e-7 of the O(1) mesh size (the 2-D chain has near-zero coordinates and a
+    # flat gauge direction along which independent solvers stop a few 1e-8 apart)
+    np.testing.assert_allclose(nic.deform(P2, w, v).cpu().numpy(), dd_ref, rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(nic.deform(P2, w, v).cpu().numpy(), nic.deform(P1, w, v).cpu().numpy(), rtol=RTOL, atol=1e-7)
