@@ -82,11 +82,13 @@ def _worker(rank, world, port, q, nx, ny, mode):
         from icp_amd import nicp_dist as nd
         v, edges, tgt, nbr, wt, nn = _problem(nx, ny)
         sh = nd.ShardedNICP(v, nbr, wt, edges, tgt)
+        if mode == "solve_rich":
+            os.environ["ICP_NICP_COARSE"] = "10"          # enriched coarse space on a small mesh: 62-double all-reduces
         if mode == "solve_ext":
             wts, lms = _extension(v, edges)
             sh.set_weights(**wts)
             sh.set_landmarks(**lms)
-        if mode in ("solve", "solve_ext"):
+        if mode in ("solve", "solve_ext", "solve_rich"):
             st = sh.solve(sh.ctx.to_dev(sh.shard.localize(nn, 3)), C, TIGHT)
             out = dict(st=st)
         else:
@@ -164,6 +166,29 @@ def test_world2_extended_energy_matches_single():
     np.testing.assert_allclose(st["err0"], st_ref["err0"], rtol=1e-12)
     np.testing.assert_allclose(st["err"], st_ref["err"], rtol=1e-9)
     np.testing.assert_allclose(dd, orc.deform(P_ref, nbr, wt, v), rtol=1e-6, atol=1e-8)
+
+
+def test_world2_enriched_coarse_space_matches_single(monkeypatch):
+    """The polynomial-enriched coarse space through the sharded solve: the 60 moments Z^T r are block sums over
+    owned vertices, all-reduced with r.z and r.r; the basis (centre, radius) comes from all-reduced sums, so both
+    ranks build the same one and take the same decisions."""
+    nx, ny = 14, 12
+    v, edges, tgt, nbr, wt, nn = _problem(nx, ny)
+    n = v.shape[0]
+    monkeypatch.setenv("ICP_NICP_COARSE", "10")
+    P_ref, st_ref = _single(v, edges, nbr, wt, nn, TIGHT)
+    monkeypatch.setenv("ICP_NICP_COARSE", "1")
+    P_plain, st_plain = _single(v, edges, nbr, wt, nn, TIGHT)
+    monkeypatch.delenv("ICP_NICP_COARSE")
+    assert st_ref["cg_iters"] != st_plain["cg_iters"]                      # the other preconditioner really ran
+    res = _run_world(2, nx, ny, "solve_rich")
+    P, dd = _assemble(res, n)
+    st = res[0]["st"]
+    assert res[1]["st"] == st
+    print("single", st_ref, "sharded", st)
+    np.testing.assert_allclose(st["err"], st_ref["err"], rtol=1e-9)
+    np.testing.assert_allclose(dd, orc.deform(P_ref, nbr, wt, v), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(dd, orc.deform(P_plain, nbr, wt, v), rtol=1e-6, atol=1e-8)
 
 
 def test_world2_outer_loop_matches_single():
