@@ -61,6 +61,38 @@ def test_nicp3d_cli_full_nicp(tmp_path):
     np.testing.assert_allclose(dd, dd_o, rtol=1e-4, atol=1e-5)
 
 
+def test_nicp3d_cli_landmarks(tmp_path):
+    """--landmarks through the C++ host (nicp3d::landmarkVertex / landmarkPos / cLand -> nicp_set_landmarks)
+    equals the Python host's run with the same landmark rows."""
+    from icp_amd import nicp
+    g = golden("nicp_step_24")
+    v, edges, tgt = g["v"], g["edges"], g["tgt"]
+    lm_v = np.array([3, 11, 20], np.int32)
+    lm_p = v[lm_v] + np.array([[0.05, 0.0, 0.02], [0.0, -0.04, 0.0], [0.03, 0.03, -0.03]])
+    write_obj(tmp_path / "s.obj", v, edges)
+    write_obj(tmp_path / "t.obj", tgt, [])
+    with open(tmp_path / "lm.txt", "w") as f:
+        for k, pnt in zip(lm_v, lm_p):
+            f.write("%d %.17g %.17g %.17g\n" % (k, pnt[0], pnt[1], pnt[2]))
+    out = subprocess.run([CLI, str(tmp_path / "s.obj"), str(tmp_path / "t.obj"), str(tmp_path / "o.obj"),
+                          "--nicp", "0.01", "3", "--fixed", "--landmarks", str(tmp_path / "lm.txt"), "50"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    dd = read_obj_vertices(tmp_path / "o.obj")
+    w = nicp.knn_weights(v)
+    w.set_landmarks(edges, lm_v, lm_p, 50.0)
+    ddp, _, _ = nicp.nicp(nicp.initial_params(len(v), 3), w, v, edges, tgt, 0.01, 3, (0.1, 1000.0, 100.0), compat=False)
+    np.testing.assert_allclose(dd, ddp.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    w0 = nicp.knn_weights(v)
+    dd0, _, _ = nicp.nicp(nicp.initial_params(len(v), 3), w0, v, edges, tgt, 0.01, 3, (0.1, 1000.0, 100.0), compat=False)
+    assert np.abs(dd[lm_v] - lm_p).max() < 0.7 * np.abs(dd0.cpu().numpy()[lm_v] - lm_p).max()   # the landmarks pull
+    # landmarks make no sense in the reference's quirk mode: refused with a message
+    bad = subprocess.run([CLI, str(tmp_path / "s.obj"), str(tmp_path / "t.obj"), str(tmp_path / "o2.obj"),
+                          "--nicp", "0.01", "3", "--landmarks", str(tmp_path / "lm.txt"), "50"],
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "COMPAT" in bad.stderr
+
+
 def test_nicp_row_module():
     from icp_amd import nicp_row
     g = golden("nicp_row_20")
