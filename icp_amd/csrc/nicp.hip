@@ -20,6 +20,7 @@
 //   Q7 (2-D) b-columns of the fit block carry no weight factor.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -2406,6 +2407,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
     const int nbp = grid_for(d.np);
     const int64_t nown = par_in.nown;
     int coarse_switch_to = 1;  // coarse-space size to move to once CG gets long (see below)
+    const bool trace = getenv("ICP_NICP_TRACE") != nullptr && par_in.rank() == 0;  // one line per LM trial on stderr
 
     // ---- solver-internal, lane-transposed copies of the inputs (see Strides)
     if (int rc = refuse_compat_weights(w, compat)) return rc;
@@ -2681,6 +2683,9 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             const double pred = lam * dn2 - dg;  // = |r|^2 - |r + J delta|^2 - lam|D delta|^2 ... >= 0 for an exact solve
             const double actred = f2 - f2t;
             const double ratio = pred > 0 ? actred / pred : (actred > 0 ? 1.0 : -1.0);
+            if (trace)
+                std::fprintf(stderr, "nicp_solve lm %3d  f2 %.12e -> %.12e  lam %.3e  cg %5d (stop %d)  pred %.3e  actred %.3e  ratio %.4f  |g| %.3e  M %d\n",
+                             it, f2, f2t, lam, hs.iters, hs.stop, pred, actred, ratio, std::sqrt(gg), w.pb.M);
             if (f2t == f2t && ratio > 1e-4) {
                 // accept (lmder accepts at ratio >= 1e-4)
                 ICP_HIP_CHECK(hipMemcpyAsync(x, w.x_trial, d.np * sizeof(double), hipMemcpyDeviceToDevice, st));
