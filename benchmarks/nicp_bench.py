@@ -3,7 +3,7 @@
 the decreasing stiffness schedule).  Not the driver's bench.py; prints one JSON line with
 outer-iterations/s and CG-iterations/s.
 
-  python benchmarks/nicp_bench.py [--nx 100 --ny 100] [--run 50] [--fixed] [--lm 100] [--cgtol 1e-10]
+  python benchmarks/nicp_bench.py [--nx 100 --ny 100] [--run 50] [--fixed] [--lm 100] [--cgtol 0]
 """
 import argparse
 import json
@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--tol", type=float, default=0.01)
     ap.add_argument("--fixed", action="store_true", help="self-consistent mode instead of reference_compat")
     ap.add_argument("--lm", type=int, default=100)
-    ap.add_argument("--cgtol", type=float, default=1e-10)
+    ap.add_argument("--cgtol", type=float, default=0.0, help="0 = the library default (automatic)")
     args = ap.parse_args()
     import torch
     from icp_amd import nicp

@@ -220,7 +220,8 @@ int nicp_jtvp(icp_ctx *ctx, nicp_graph *g, const double *P, const double *v, con
 typedef struct nicp_solve_opts {
     double ftol, xtol, gtol; /* MINPACK-style relative tolerances; leastsq defaults 1.49012e-8, 1.49012e-8, 0 */
     double lambda0;          /* initial Levenberg-Marquardt damping (1e-3) */
-    double cg_tol;           /* relative residual of the inner conjugate-gradient solve (1e-10) */
+    double cg_tol;           /* relative residual of the inner conjugate-gradient solve; <= 0 (default): automatic,
+                                min(1e-4, sqrt(min(ftol, xtol))) */
     int max_lm_iters;        /* outer iterations (100) */
     int max_cg_iters;        /* per linear solve (0 = automatic) */
 } nicp_solve_opts;
