@@ -2414,6 +2414,8 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
     const int nbp = grid_for(d.np);
     const int64_t nown = par_in.nown;
     int coarse_switch_to = 1;  // coarse-space size to move to once CG gets long (see below)
+    int e_lag = 8, e_age = -1, e_M = 0;  // coarse-matrix reuse: rebuilt every 8th linear solve (ICP_NICP_ELAG overrides)
+    if (const char *e = getenv("ICP_NICP_ELAG")) e_lag = std::max(1, atoi(e));
     const bool trace = getenv("ICP_NICP_TRACE") != nullptr && par_in.rank() == 0;  // one line per LM trial on stderr
 
     // ---- solver-internal, lane-transposed copies of the inputs (see Strides)
@@ -2537,7 +2539,14 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                                              (const Globals *)w.glob, c[0], c[1], c[2], (const double *)w.col2, (const double *)w.d2, lam,
                                              w.binv, w.coarse, w.st, w.rw));
             ICP_HIP_CHECK(hipGetLastError());
-            for (int a = 0; a < nz; ++a) {  // E[:, a] = Z^T (J^T J + lam D^2) z_a
+            // The coarse matrix may lag: any symmetric positive (semi-)definite E^+ keeps the preconditioner valid, and
+            // between consecutive LM steps of a long solve E barely moves, so it is rebuilt every `e_lag`-th linear
+            // solve only (and whenever the coarse space changes); the vertex blocks are always current.
+            const bool rebuild_E = e_age < 0 || e_age >= e_lag || e_M != w.pb.M;
+            if (rebuild_E) e_age = 0;
+            ++e_age;
+            e_M = w.pb.M;
+            for (int a = 0; rebuild_E && a < nz; ++a) {  // E[:, a] = Z^T (J^T J + lam D^2) z_a
                 if (g->dim == 3) hipLaunchKernelGGL(zcol_kernel<3>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z, w.st, w.pb);
                 else hipLaunchKernelGGL(zcol_kernel<2>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z, w.st, w.pb);
                 if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.z, w.y, 1)) return rc;
@@ -2551,7 +2560,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 hipLaunchKernelGGL(ecol_logic_kernel, dim3(1), dim3(128), 0, st, (const double *)par.tot, d.NG, nm, d2_tail, lam, a, w.coarse);
             }
             ICP_HIP_CHECK(hipGetLastError());
-            {
+            if (rebuild_E) {
                 double E[NZMAX * NZMAX], Einv[NZMAX * NZMAX];
                 ICP_HIP_CHECK(hipMemcpyAsync(E, w.coarse->E, sizeof(double) * nz * nz, hipMemcpyDeviceToHost, st));
                 ICP_HIP_CHECK(hipStreamSynchronize(st));
@@ -2561,6 +2570,9 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                     std::memset(Einv, 0, sizeof(Einv));  // fall back to the block level alone
                 }
                 ICP_HIP_CHECK(hipMemcpyAsync(w.coarse->Einv, Einv, sizeof(double) * nz * nz, hipMemcpyHostToDevice, st));
+                ICP_HIP_CHECK(hipStreamSynchronize(st));  // the source is on this stack frame
+            }
+            {
                 const double tol2 = cg_tol_now * cg_tol_now;
                 ICP_HIP_CHECK(hipMemcpyAsync(&w.coarse->tol2, &tol2, sizeof(double), hipMemcpyHostToDevice, st));
                 ICP_HIP_CHECK(hipStreamSynchronize(st));  // both sources are on this stack frame
