@@ -1247,8 +1247,10 @@ __global__ __launch_bounds__(1024) void cg_sum_alpha_kernel(const double *__rest
 }
 
 // tail update, coarse solve y = Einv Z^T r, r.z, beta, stop test.  tot[0] r.zb, tot[1] r.r, tot[2..2+ng) Z_v^T r
+// tails_done: the (fused) update kernel has already advanced x / r / zb of the tail entries; only read them here
 __device__ __forceinline__ void coarse_logic(const double *tot, int ng, int nm, double *x_tail, double *r_tail, double *zb_tail,
-                                             const double *p_tail, const double *Ap_tail, Coarse *coarse, Scal *s, int init) {
+                                             const double *p_tail, const double *Ap_tail, Coarse *coarse, Scal *s, int init,
+                                             int tails_done = 0) {
     const int tid = threadIdx.x;
     const int stop = s->stop;  // uniform: only thread 0 writes it, at the very end
     if (stop) return;
@@ -1258,11 +1260,17 @@ __device__ __forceinline__ void coarse_logic(const double *tot, int ng, int nm, 
         double rz = tot[0], rr = tot[1];
         const double alpha = s->alpha;
         for (int k = 0; k < ng; ++k) {
-            x_tail[k] += alpha * p_tail[k];
-            const double rt = r_tail[k] - alpha * Ap_tail[k];
-            r_tail[k] = rt;
-            const double zt = rt * coarse->tail_minv[k];
-            zb_tail[k] = zt;
+            double rt, zt;
+            if (tails_done) {
+                rt = r_tail[k];
+                zt = zb_tail[k];
+            } else {
+                x_tail[k] += alpha * p_tail[k];
+                rt = r_tail[k] - alpha * Ap_tail[k];
+                r_tail[k] = rt;
+                zt = rt * coarse->tail_minv[k];
+                zb_tail[k] = zt;
+            }
             rz += rt * zt;
             rr += rt * rt;
             ztr_s[nm + k] = rt;
@@ -1340,14 +1348,14 @@ __global__ __launch_bounds__(1024) void cg_sum_coarse_kernel(const double *__res
                                                              double *__restrict__ r_tail, double *__restrict__ zb_tail,
                                                              const double *__restrict__ p_tail, const double *__restrict__ Ap_tail,
                                                              Coarse *__restrict__ coarse, Scal *__restrict__ s, int init,
-                                                             const double *__restrict__ mom, int nm) {
+                                                             const double *__restrict__ mom, int nm, int tails_done) {
     // the sums stay in LDS (no round trip through `tot`, which nothing else reads on the single-GPU path)
     __shared__ double tot_s[2 + kMomSlots];
     (void)tot;
     block_rows_sum(partial, nb, mask, tot_s, 0);
     if (mom) block_rows_sum_wide(mom, nb, nm, tot_s, 2);
     __syncthreads();
-    coarse_logic(tot_s, ng, nm, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s, init);
+    coarse_logic(tot_s, ng, nm, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s, init, tails_done);
 }
 
 // tot[slot] += sum_k a[k] b[k] (w ? w[k] : 1) over the ng replicated tail entries (added on one rank only)
@@ -1411,10 +1419,10 @@ struct FusedCg {
     const double *lamd2_tail;
     double *x_tail, *r_tail, *zb_tail, *Ap_tail;
     const double *p_tail;
-    int parity;
+    int parity;  // which Scal::tmp slot holds r.z (see above); -1: the direction stage is NOT fused, r.z is Scal::rz
 };
 
-template <int DIM, bool FUSED>
+template <int DIM, bool FUSED, bool RICH>
 __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s, const double *__restrict__ P,
                                                            const double *__restrict__ v, int64_t n,
                                                            double *__restrict__ x, double *__restrict__ r,
@@ -1446,7 +1454,7 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
                     apt[k] = val;
                     pap += val * f.p_tail[k];
                 }
-                alpha = pap > 0 ? s->tmp[f.parity] / pap : 0.0;
+                alpha = pap > 0 ? (f.parity >= 0 ? s->tmp[f.parity] : s->rz) / pap : 0.0;
                 if (!(pap > 0)) stop = 2;  // breakdown (non-positive curvature / NaN)
                 if (blockIdx.x == 0) {
                     s->pAp = pap;
@@ -1506,7 +1514,7 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
             }
         double z[NG][S];
         zmodes<DIM>(Pj_, vj_, z);
-        if (!FUSED && pb.M > 1) poly_eval<DIM>(vj_, pb, phi);
+        if constexpr (RICH) poly_eval<DIM>(vj_, pb, phi);
 #pragma unroll
         for (int e = 0; e < S; ++e) {
             acc[0] += rj[e] * zj[e];
@@ -1534,7 +1542,7 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t += red[w][tid];
         partial[(int64_t)blockIdx.x * kSumSlots + tid] = t;
     }
-    if (!FUSED && pb.M > 1) {  // enriched coarse space: the NG*M moments of the new residual
+    if constexpr (RICH) {  // enriched coarse space: the NG*M moments of the new residual
         double tk[NG];
 #pragma unroll
         for (int k = 0; k < NG; ++k) tk[k] = acc[2 + k];
@@ -2585,23 +2593,26 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             ICP_HIP_CHECK(hipMemsetAsync(w.scal, 0, sizeof(Scal), st));
             const double *lamd2_tail = w.lamd2 + d.n * d.S;
             const bool fused = !par.sharded() && fused_enabled && !rich;  // see FusedCg (plain coarse space only)
+            const bool mixed = !par.sharded() && fused_enabled && rich;   // enriched space: alpha stage fused, coarse stage its own launch
             // slots of the update kernel's partial rows that the sums read: r.zb, r.r (+ the NG plain moments)
             const unsigned upd_mask = rich ? 0x3u : (1u << (2 + d.NG)) - 1u;
             auto precondition = [&](int init, int parity) -> int {
-                const bool fz = fused && !init;
-                FusedCg fa = {w.partial, nbj, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, parity};
+                const bool fz = fused && !init;            // both stages fused (plain coarse space)
+                const bool fzu = (fused || mixed) && !init;  // the update kernel derives alpha itself
+                FusedCg fa = {w.partial, nbj, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, fused ? parity : -1};
                 FusedCg fb = {w.partial2, nbv, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, parity};
-                double *upd_partial = fz ? w.partial2 : w.partial;
-#define NICP_UPD(D, F) hipLaunchKernelGGL((cg_update_prec_kernel<D, F>), dim3(nbv), dim3(g->vb), 0, st, w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, upd_partial, nown, w.st, (const Coarse *)w.coarse, fa, w.mom, w.pb)
+                double *upd_partial = fzu ? w.partial2 : w.partial;
+#define NICP_UPD(D, F) if (rich) NICP_UPD2(D, F, true); else NICP_UPD2(D, F, false)
+#define NICP_UPD2(D, F, R) hipLaunchKernelGGL((cg_update_prec_kernel<D, F, R>), dim3(nbv), dim3(g->vb), 0, st, w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, upd_partial, nown, w.st, (const Coarse *)w.coarse, fa, w.mom, w.pb)
 #define NICP_DIR(D, F) hipLaunchKernelGGL((cg_dir_prec_kernel<D, F>), dim3(nbt), dim3(g->vb), 0, st, w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown, w.st, fb, w.pb)
-                if (g->dim == 3) { if (fz) NICP_UPD(3, true); else NICP_UPD(3, false); }
-                else { if (fz) NICP_UPD(2, true); else NICP_UPD(2, false); }
+                if (g->dim == 3) { if (fzu) { NICP_UPD(3, true); } else { NICP_UPD(3, false); } }
+                else { if (fzu) { NICP_UPD(2, true); } else { NICP_UPD(2, false); } }
                 if (fz) {
                     // sums + coarse solve happen inside the direction kernel
                 } else if (!par.sharded()) {
-                    hipLaunchKernelGGL(cg_sum_coarse_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, upd_mask,
+                    hipLaunchKernelGGL(cg_sum_coarse_kernel, dim3(1), dim3(1024), 0, st, (const double *)upd_partial, nbv, upd_mask,
                                        par.tot, d.NG, x_tail, r_tail, zb_tail, (const double *)p_tail, (const double *)Ap_tail, w.coarse,
-                                       w.scal, init, (const double *)(rich ? w.mom : nullptr), nm);
+                                       w.scal, init, (const double *)(rich ? w.mom : nullptr), nm, fzu ? 1 : 0);
                 } else {
                     hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbv, upd_mask, par.tot, 0);
                     if (rich) hipLaunchKernelGGL(rows_sum_wide_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.mom, nbv, nm, par.tot, 2);
@@ -2612,6 +2623,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 if (g->dim == 3) { if (fz) NICP_DIR(3, true); else NICP_DIR(3, false); }
                 else { if (fz) NICP_DIR(2, true); else NICP_DIR(2, false); }
 #undef NICP_UPD
+#undef NICP_UPD2
 #undef NICP_DIR
                 return exchange(ctx, g, w, par, w.pcg);
             };
@@ -2624,7 +2636,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 for (int k = 0; k < count; ++k) {
                     if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.pcg, w.y, 1)) return rc;
                     if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.y, w.lamd2, w.pcg, 1.0, w.Ap, false, false)) return rc;
-                    if (fused) {
+                    if (fused || mixed) {
                         // the update kernel sums the partials and derives alpha itself
                     } else if (!par.sharded()) {
                         hipLaunchKernelGGL(cg_sum_alpha_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask | (1u << 8),

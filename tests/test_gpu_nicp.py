@@ -331,3 +331,25 @@ def test_enriched_coarse_space_same_minimiser(mods, monkeypatch, name, coarse):
     # flat gauge direction along which independent solvers stop a few 1e-8 apart)
     np.testing.assert_allclose(nic.deform(P2, w, v).cpu().numpy(), dd_ref, rtol=RTOL, atol=1e-7)
     np.testing.assert_allclose(nic.deform(P2, w, v).cpu().numpy(), nic.deform(P1, w, v).cpu().numpy(), rtol=RTOL, atol=1e-7)
+
+
+def test_enriched_fused_alpha_stage_is_bit_identical(mods, monkeypatch):
+    """Enriched coarse space on a small mesh: the alpha stage folded into the update kernel (default) against the
+    six-launch form (ICP_NICP_FUSED=0), with and without the graph replay -- same kernels' arithmetic, same bits."""
+    v, edges, tgt = orc.make_grid_mesh(40, 36, seed=11)
+    nic = mods["nicp"]
+    w = nic.knn_weights(v)
+    nn = tgt[c_oracle.match_idx(v, tgt)[0]]
+    P0 = nic.initial_params(len(v), 3)
+    opts = dict(max_lm_iters=3, cg_tol=1e-8)
+    monkeypatch.setenv("ICP_NICP_COARSE", "10")
+    out = []
+    for fused, graph in (("1", "0"), ("0", "0"), ("1", "1"), ("0", "1")):
+        monkeypatch.setenv("ICP_NICP_FUSED", fused)
+        monkeypatch.setenv("ICP_NICP_GRAPH", graph)
+        P, st = nic.solve(P0, w, v, edges, nn, C, compat=False, opts=opts)
+        out.append((P.cpu().numpy(), st))
+    for P, st in out[1:]:
+        assert np.array_equal(P, out[0][0])
+        assert all(st[k] == out[0][1][k] for k in ("err", "err0", "lm_iters", "cg_iters", "nfev", "info"))
+    assert out[0][1]["cg_iters"] >= 50
