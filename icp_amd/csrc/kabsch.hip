@@ -33,6 +33,28 @@ struct RigidState {
     int32_t iters;
 };
 
+// Row range of a block in the streaming kernels below.  Workgroups are dealt round-robin over the 8 XCDs (blocks b
+// and b + 8 share an L2): XCD k takes the k-th contiguous eighth of the rows and its blocks stride through it, so
+// the gathers tgt[idx[i]] of one L2 stay within about an eighth of the (Morton-coherent) target instead of all of it
+// (2^20 points: both kernels -14 %; 2^24: within +-5 %).
+struct RowWalk {
+    int64_t begin, end, step;
+};
+__device__ __forceinline__ RowWalk row_walk(int64_t n, int block_threads) {
+    RowWalk w;
+    if ((gridDim.x & 7u) == 0 && n >= (int64_t)gridDim.x * block_threads) {
+        const int64_t seg = (n + 7) / 8, i0 = (int64_t)(blockIdx.x & 7) * seg;
+        w.begin = i0 + (int64_t)(blockIdx.x >> 3) * block_threads + threadIdx.x;
+        w.end = i0 + seg < n ? i0 + seg : n;
+        w.step = (int64_t)(gridDim.x >> 3) * block_threads;
+    } else {
+        w.begin = (int64_t)blockIdx.x * block_threads + threadIdx.x;
+        w.end = n;
+        w.step = (int64_t)gridDim.x * block_threads;
+    }
+    return w;
+}
+
 template <int NS>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NS], double *__restrict__ out) {
     __shared__ double red[RB / 64][NS];
@@ -67,7 +89,8 @@ __global__ __launch_bounds__(RB) void shard_sums_kernel(const double *__restrict
         c_s[c] = cs[c];
         c_t[c] = ct[c];
     }
-    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += (int64_t)gridDim.x * RB) {
+    const RowWalk rw = row_walk(n, RB);
+    for (int64_t i = rw.begin; i < rw.end; i += rw.step) {
         const int64_t j = GATHER ? (int64_t)idx[i] : i;
         double s[DIM], t[DIM];
 #pragma unroll
@@ -293,7 +316,8 @@ __global__ __launch_bounds__(RB) void apply_err_kernel(const double *__restrict_
         }
     }
     double acc[1] = {0.0};
-    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += (int64_t)gridDim.x * RB) {
+    const RowWalk rw = row_walk(n, RB);
+    for (int64_t i = rw.begin; i < rw.end; i += rw.step) {
         double s[DIM], o[DIM];
 #pragma unroll
         for (int c = 0; c < DIM; ++c) s[c] = src[i * DIM + c];

@@ -121,7 +121,9 @@ def test_weighted_solve_vs_leastsq(nic, name):
     dd = nic.deform(P, w, v).cpu().numpy()
     print(name, "extended energy: leastsq", e_ref, "gpu", st)
     np.testing.assert_allclose(st["err"], e_ref, rtol=1e-6)
-    np.testing.assert_allclose(dd, dd_ref, rtol=RTOL, atol=1e-8)
+    # 1e-6 relative with an absolute floor of 1e-7 of the O(1) mesh size: vertices without a fit term leave nearly flat
+    # directions, along which scipy's own result moves by several 1e-8 from run to run (threaded BLAS in the oracle)
+    np.testing.assert_allclose(dd, dd_ref, rtol=RTOL, atol=1e-7)
     # the landmarks pull: with a large c_land the landmark vertices land on their positions
     w.set_landmarks(edges, ext["lm_vertex"], ext["lm_pos"], 1e4)
     P2, st2 = nic.solve(P0, w, v, edges, nn, C, compat=False)
