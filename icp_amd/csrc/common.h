@@ -53,6 +53,8 @@ struct icp_ctx {
     icp::Scratch grid_a, grid_b, grid_c, grid_d, grid_e;  // spatial grid over the target
     icp::Scratch sort_a, sort_b, sort_c, sort_d;          // Morton order of the queries
     icp::Scratch defer;                                   // grid search: queries handed to the wave-per-query pass
+    void *defer_cleared = nullptr;                        // buffer whose two counters are known to be in step
+    int defer_parity = 0;                                 // which of the two counters the next search uses
     // nicp_solve replays its CG iterations as a hipGraph; graphs cannot be captured on the legacy
     // default stream (which `stream` may be), so they are captured and launched on this one
     hipStream_t side = nullptr;
