@@ -171,3 +171,30 @@ def test_grid_inside_icp_2d_and_sqrt(rigid, dim, compare_sqrt):
     np.testing.assert_allclose(a["T"].cpu().numpy(), b["T"].cpu().numpy(), rtol=1e-12, atol=1e-13)
     n = int(a["iters"].cpu()[0])
     np.testing.assert_allclose(a["err_hist"].cpu().numpy()[:n], b["err_hist"].cpu().numpy()[:n], rtol=1e-11)
+
+
+def test_deferred_counters_survive_early_stop_and_resizing(rigid):
+    """The deferred-query list has two counters used alternately, each cleared by the deferred pass of the
+    search before.  Searches that return at once (run stopped by its tolerance, an odd and an even number
+    of them) and a larger cloud that reallocates the list in between must leave every later search exact."""
+    rng = np.random.default_rng(5)
+    cl = np.concatenate([rng.standard_normal((6000, 3)) * 0.01 + c for c in rng.uniform(-5, 5, (6, 3))])
+    far = np.concatenate([rng.uniform(-20, 20, (4000, 3)), cl[:3000] + 1e-3])   # many deferred queries
+    oi, od = c_oracle.match_idx(far, cl)
+
+    def check():
+        gi, gd = rigid.closest_indices(far, cl, want_d2=True, force_grid=True)
+        assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gd.cpu().numpy(), od)
+
+    check()
+    src, tgt = orc.make_rigid_cloud(20000, seed=3)
+    for run in (40, 41):     # both stop after a few iterations: the rest of the enqueued searches are no-ops
+        out = rigid.rigid_icp(src, tgt, 0.10, run, force_grid=True)
+        assert int(out["iters"].cpu()[0]) < run - 2
+        check()
+        check()
+    big_s, big_t = orc.make_rigid_cloud(150000, seed=4)    # the list grows: counters start afresh
+    a = rigid.rigid_icp(big_s, big_t, 0.10, 30, want_idx=True, force_grid=True)
+    b = rigid.rigid_icp(big_s, big_t, 0.10, 30, want_idx=True, force_brute=True)
+    assert np.array_equal(a["idx"].cpu().numpy(), b["idx"].cpu().numpy())
+    check()
