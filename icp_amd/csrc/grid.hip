@@ -259,10 +259,15 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                                                        int pos_mode, int xcd_chunk) {
     if (done && *done) return;
     // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), each
-    // with its own 4 MiB L2.  The queries arrive in Morton order, so giving XCD k the k-th contiguous eighth of them
-    // confines its gathers to about an eighth of the sorted target records (~4 MB at 2^20 targets) instead of letting
-    // every L2 stream the whole array.  xcd_chunk = blocks per XCD; the launch has 8 * xcd_chunk blocks.
-    const int64_t blk = xcd_chunk > 0 ? (int64_t)(blockIdx.x & 7) * xcd_chunk + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    // with its own 4 MiB L2, and the queries arrive in Morton order.  The launch is cut into super-chunks of
+    // 8 * xcd_chunk consecutive blocks; inside one, XCD k takes the k-th run of xcd_chunk consecutive blocks, so the
+    // blocks resident in one XCD at a time are neighbours in space and share target records in its L2 (host side,
+    // grid_query(): how xcd_chunk is chosen, with the measurements).
+    int64_t blk = blockIdx.x;
+    if (xcd_chunk > 0) {
+        const uint32_t per = 8u * (uint32_t)xcd_chunk, sc = blockIdx.x / per, r = blockIdx.x - sc * per;
+        blk = (int64_t)sc * per + (int64_t)(r & 7u) * xcd_chunk + (r >> 3);
+    }
     const int64_t t = blk * QB + threadIdx.x;
     if (t >= n) return;
     const long long t_begin = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -923,10 +928,23 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
     if (cap < 1000) ctx->defer_parity ^= 1;
     static const int xcd_env = getenv("ICP_GRID_XCD") ? atoi(getenv("ICP_GRID_XCD")) : 1;
     unsigned nb = (unsigned)((n + 255) / 256);
-    // pays while an eighth of the 32-byte records is of the order of one L2 (measured: 2^20 targets -3.6 %, 2^21 +2 %,
-    // 2^23 +6 %, 2^24 +15 %: beyond that the XCDs do better sweeping the SAME region together and sharing the Infinity Cache)
-    const int xcd_chunk = xcd_env && nb >= 64 && gb.m * 32 <= (int64_t)48 << 20 ? (int)((nb + 7) / 8) : 0;
-    if (xcd_chunk) nb = 8u * (unsigned)xcd_chunk;
+    // xcd_chunk = consecutive blocks (of consecutive Morton-ordered queries) that one XCD takes; 8 * xcd_chunk blocks
+    // form a super-chunk.  While an eighth of the 32-byte records is of the order of one L2 (<= 1.5 M targets) one
+    // super-chunk spans the whole search: XCD k works on the k-th eighth of the queries (2^20 x 2^20: -6 % time, HBM
+    // traffic 210 -> 109 MB).  Beyond that size that form LOSES (2^21: +4 %, 2^24: +3 %: the XCDs drift apart and stop
+    // sharing the Infinity Cache) and short runs of 32 blocks win instead: the blocks that are resident in one XCD at
+    // the same time are then neighbours in query order and share their neighbourhood's records in L2, while all XCDs
+    // stay in one region of the target (2^21: -5 %, 2^22: -4 %, 2^24: -5 %; 8 / 16 / 32 within 1 % of each other; at
+    // 2^20 runs of 32 are as fast as the eighths but fetch 126 MB).  ICP_GRID_XCD=0: plain order; N > 1: runs of N.
+    int xcd_chunk = 0;
+    if (xcd_env && nb >= 64) {
+        const unsigned eighth = (nb + 7) / 8;
+        unsigned c = gb.m * 32 <= (int64_t)48 << 20 ? eighth : 32u;
+        if (xcd_env > 1) c = (unsigned)xcd_env;
+        xcd_chunk = (int)(c < eighth ? c : eighth);
+        const unsigned per = 8u * (unsigned)xcd_chunk;
+        nb = (nb + per - 1) / per * per;            // blocks past the end return at once
+    }
     unsigned nb2 = n < 8192 ? (unsigned)n : 8192u;   // one wave per deferred query, at most
 #define ICP_GQ(D, L) \
     do { \
