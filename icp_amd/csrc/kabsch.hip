@@ -559,11 +559,7 @@ extern "C" int icp_gather_points(icp_ctx *ctx, const double *tgt, const int32_t 
 extern "C" int icp_distance_sum(icp_ctx *ctx, const double *a, const double *b, int64_t n, int dim, double *out_dev) {
     ICP_COMMON_ARGS(ctx, dim);
     ICP_REQUIRE(a && b && out_dev && n >= 0, "bad argument");
-    if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
-    double *tmp = (double *)ctx->small.ptr + 256;  // 16 scratch doubles
-    if (int rc = apply_err(ctx, 2, b, a, nullptr, n, dim, nullptr, nullptr, nullptr, tmp, nullptr)) return rc;
-    ICP_HIP_CHECK(hipMemcpyAsync(out_dev, tmp, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    return ICP_OK;
+    return apply_err(ctx, 2, b, a, nullptr, n, dim, nullptr, nullptr, nullptr, out_dev, nullptr);
 }
 
 extern "C" int icp_column_sums(icp_ctx *ctx, const double *a, int64_t n, int dim, double *out_dev) {
@@ -616,11 +612,8 @@ extern "C" int icp_shard_apply_err(icp_ctx *ctx, const double *src, const double
                                    int dim, const double *R_dev, const double *t_dev, double *ss_out, double *err_out_dev) {
     ICP_COMMON_ARGS(ctx, dim);
     ICP_REQUIRE(src && tgt && idx && R_dev && t_dev && err_out_dev && n >= 0, "bad argument");
-    if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
-    double *tmp = (double *)ctx->small.ptr + 256;
-    if (int rc = apply_err(ctx, 1, src, tgt, idx, n, dim, R_dev, t_dev, ss_out, tmp, nullptr)) return rc;
-    ICP_HIP_CHECK(hipMemcpyAsync(err_out_dev, tmp, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    return ICP_OK;
+    // the reduction writes its one result straight to the caller's slot (no staging copy: one launch less per iteration)
+    return apply_err(ctx, 1, src, tgt, idx, n, dim, R_dev, t_dev, ss_out, err_out_dev, nullptr);
 }
 
 extern "C" int icp_rigid_run(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
