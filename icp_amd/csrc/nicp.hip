@@ -358,6 +358,24 @@ __global__ __launch_bounds__(NB) void residual_kernel(const double *__restrict__
     }
 }
 
+// XCD-aware block order of the per-vertex CG kernels.  Workgroups are dealt round-robin over the 8 XCDs, each with its own
+// L2, and the vertices are in Morton order: with the plain order the blocks that share an L2 are 8 apart, so every
+// neighbour gather that crosses a block boundary (p, u of adjacent vertices, edge rows) lands in ANOTHER XCD's L2 and is
+// fetched again.  The launch is cut into super-chunks of 8 * R blocks in which XCD k takes the k-th run of R consecutive
+// logical blocks.  Only which physical block does which logical block changes: rows, partial slots and all results are
+// bit-identical.  R = 16 measured per CG iteration: 10 k vertices 43.4 -> 41.1 us, 65 k 82.3 -> 74.5, 200 k 225 -> 206,
+// 640 k 675 -> 628 (R = 8 ... 32 within 1 %; contiguous EIGHTHS of the mesh per XCD were slower than the plain order,
+// 229 -> 252 us at 200 k: the XCDs then stop sharing the Infinity Cache).  ICP_NICP_RUN=0 restores the plain order.
+__device__ int g_nicp_run = 16;
+__device__ __forceinline__ unsigned vblock() {
+    const int R = g_nicp_run;
+    if (R <= 0) return blockIdx.x;
+    const unsigned per = 8u * (unsigned)R, sc = blockIdx.x / per;
+    if ((sc + 1u) * per > gridDim.x) return blockIdx.x;   // ragged last super-chunk: plain order
+    const unsigned r = blockIdx.x - sc * per;
+    return sc * per + (r & 7u) * (unsigned)R + (r >> 3);
+}
+
 // ------------------------------------------------------------------ y = J p
 template <int DIM, bool COMPAT>
 __global__ __launch_bounds__(NB) void jp_kernel(const double *__restrict__ P, const double *__restrict__ p,
@@ -369,7 +387,7 @@ __global__ __launch_bounds__(NB) void jp_kernel(const double *__restrict__ P, co
     // sq = 0: y = W J p (rows as nicp_residual, landmark rows included); sq = 1: y = W^2 J p with the
     // landmark rows folded into the fit rows (rw.f2), which is what J^T needs next in the CG operator
     constexpr int S = Lay<DIM>::S, NRIG = Lay<DIM>::NRIG, NANG = Lay<DIM>::NANG, NA = Lay<DIM>::NA;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = (int64_t)vblock() * blockDim.x + threadIdx.x;
     double *y_rig = y + n * DIM, *y_sm = y + n * DIM + n * NRIG, *y_land = y_sm + 2 * DIM * ne;
     const double *ptail = p + n * S;
     double c_land_row = 0.0;
@@ -518,7 +536,7 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
     // the row multipliers are already in u (jp_kernel with sq = 1, weight_rows_kernel); only the
     // column sums of squares (SQUARE) read them here
     constexpr int NRIG = Lay<DIM>::NRIG, NANG = Lay<DIM>::NANG, NG = Lay<DIM>::NG;
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = (int64_t)vblock() * blockDim.x + threadIdx.x;
     const double *u_rig = u + n * DIM, *u_sm = u + n * DIM + n * NRIG;
     double gacc[kSumSlots];
 #pragma unroll
@@ -742,7 +760,7 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
     if (tid < 9 && (tid < NG || tid == 8)) {
         double s = red[0][tid];
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s += red[w][tid];
-        partial[(int64_t)blockIdx.x * kSumSlots + tid] = s;
+        partial[(j / blockDim.x) * kSumSlots + tid] = s;
     }
 }
 
@@ -1432,7 +1450,7 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
                                                            const Coarse *__restrict__ coarse, FusedCg f,
                                                            double *__restrict__ mom, PolyBasis pb) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = (int64_t)vblock() * blockDim.x + threadIdx.x;
     double acc[2 + NG], phi[MAXPOLY];
     for (int k = 0; k < 2 + NG; ++k) acc[k] = 0.0;
     for (int m = 0; m < MAXPOLY; ++m) phi[m] = 0.0;
@@ -1540,13 +1558,13 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
     if (tid < 2 + NG) {
         double t = red[0][tid];
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t += red[w][tid];
-        partial[(int64_t)blockIdx.x * kSumSlots + tid] = t;
+        partial[(j / blockDim.x) * kSumSlots + tid] = t;
     }
     if constexpr (RICH) {  // enriched coarse space: the NG*M moments of the new residual
         double tk[NG];
 #pragma unroll
         for (int k = 0; k < NG; ++k) tk[k] = acc[2 + k];
-        block_moments<DIM>(tk, phi, pb.M, mom + (int64_t)blockIdx.x * kMomSlots);
+        block_moments<DIM>(tk, phi, pb.M, mom + (j / blockDim.x) * kMomSlots);
     }
 }
 
@@ -1617,7 +1635,7 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, c
         for (int i = threadIdx.x; i < nm + NG; i += blockDim.x) y_s[i] = coarse->y[i];
         __syncthreads();
     }
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = (int64_t)vblock() * blockDim.x + threadIdx.x;
     if (j < n) {
         if (j >= nown) return;  // halo copy
         double z[NG][S], Pj_[S], vj_[DIM], zbj[S], pj[S], yk[NG];
@@ -2402,6 +2420,10 @@ static int relayout(icp_ctx *ctx, const double *src, int64_t sj, int64_t se, dou
 static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, double *P_inout, const double *v_ext,
                       const double *nn_ext, const double *c3_host, unsigned flags, const nicp_solve_opts *opts_in,
                       nicp_solve_stats *stats_out) {
+    {   // A/B switch for the block order of the CG kernels (vblock): written only when the variable is set
+        static const int run_env = getenv("ICP_NICP_RUN") ? atoi(getenv("ICP_NICP_RUN")) : -1;
+        if (run_env >= 0) ICP_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_nicp_run), &run_env, sizeof(int)));
+    }
     const bool compat = flags & 1u;
     const Dims d = dims_of(g);
     nicp_solve_opts o = {1.49012e-8, 1.49012e-8, 0.0, 1e-3, 0.0, 100, 0};
