@@ -1151,8 +1151,21 @@ __device__ __forceinline__ void block_rows_sum(const double *__restrict__ partia
                                                double *__restrict__ tot, int off) {
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k < kSumSlots && ((mask >> k) & 1u)) {
+        // the loads of 16 rows are issued before the first add: one memory latency per 1 024 block rows instead of
+        // one per 64; the additions keep their order (ascending rows per lane), so the sums keep their bits
+        constexpr int BATCH = 16;
         double a = 0.0;
-        for (int b = lane; b < nb; b += 64) a += partial[(int64_t)b * kSumSlots + k];
+        for (int b0 = lane; b0 < nb; b0 += 64 * BATCH) {
+            double t[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int b = b0 + 64 * u;
+                t[u] = b < nb ? partial[(int64_t)b * kSumSlots + k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+                if (b0 + 64 * u < nb) a += t[u];
+        }
         a = wave_sum(a);
         if (lane == 0) tot[off + k] = a;
     }
