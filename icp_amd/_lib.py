@@ -44,6 +44,7 @@ _SIGNATURES = {
     "icp_gather_points": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp],
     "icp_distance_sum": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp],
     "icp_find_transform": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_dp],
+    "icp_find_transform_noalloc": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_dp],
     "icp_apply_transform": [c_dp, c_dp, c_i64, c_int, c_dp, c_dp, c_dp],
     "icp_rigid_run": [c_dp, c_dp, c_i64, c_dp, c_i64, c_int, c_dbl, c_int, c_int, c_u32, c_dp, c_dp, c_dp, c_dp],
     "icp_shard_sums": [c_dp, c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_dp, c_dp],

@@ -59,10 +59,13 @@ struct icp_ctx {
     // default stream (which `stream` may be), so they are captured and launched on this one
     hipStream_t side = nullptr;
     hipEvent_t side_ev = nullptr;
+    // this device's address of kabsch.hip's file-scope scratch array (icp_find_transform_noalloc)
+    double *noalloc_scratch = nullptr;
 };
 
 namespace icp {
 int ensure(icp_ctx *ctx, Scratch &s, size_t bytes);
+int noalloc_init(icp_ctx *ctx);  // kabsch.hip
 
 // spatial grid over a target cloud (grid.hip)
 struct GridParams {

@@ -53,6 +53,10 @@ extern "C" int icp_ctx_create(int device, icp_ctx **out) {
     icp_ctx *ctx = new icp_ctx();
     ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (int rc = icp::noalloc_init(ctx)) {  // per-device address of the static scratch array (allocates nothing)
+        delete ctx;
+        return rc;
+    }
     *out = ctx;
     return ICP_OK;
 }

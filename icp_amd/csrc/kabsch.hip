@@ -453,25 +453,31 @@ __global__ void rigid_finish_kernel(const RigidState *st, int dim, double *T, in
     if (iters_out) *iters_out = st->iters;
 }
 
+constexpr int kRowBlocksMax = 512;  // 2 blocks per CU; the final single-block reduce stays short
 static inline int nblocks_for(int64_t n) {
     int64_t nb = (n + RB - 1) / RB;
-    if (nb > 512) nb = 512;  // 2 blocks per CU; the final single-block reduce stays short
+    if (nb > kRowBlocksMax) nb = kRowBlocksMax;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
 
-static int reduce_to(icp_ctx *ctx, int nb, double *out_dev, int nout, int mean_slots, const int32_t *done) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(RB), 0, ctx->stream, (const double *)ctx->partials.ptr, nb,
-                       out_dev, nout, mean_slots, done);
+static int reduce_to(icp_ctx *ctx, const double *part, int nb, double *out_dev, int nout, int mean_slots,
+                     const int32_t *done) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(RB), 0, ctx->stream, part, nb, out_dev, nout, mean_slots,
+                       done);
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
 }
 
+// `part` (the [kMaxPartials][kSumSlots] block-partial rows): null = the context's grow-only buffer
 static int shard_sums(icp_ctx *ctx, const double *src, const double *tgt, const int32_t *idx, int64_t n, int dim,
-                      const double *cs, const double *ct, double *sums_out, const int32_t *done, int *nb_out = nullptr) {
-    if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
+                      const double *cs, const double *ct, double *sums_out, const int32_t *done, int *nb_out = nullptr,
+                      double *part = nullptr) {
+    if (!part) {
+        if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
+        part = (double *)ctx->partials.ptr;
+    }
     const int nb = nblocks_for(n);
-    double *part = (double *)ctx->partials.ptr;
     hipStream_t st = ctx->stream;
     if (dim == 3) {
         if (idx) hipLaunchKernelGGL((shard_sums_kernel<3, true>), dim3(nb), dim3(RB), 0, st, src, tgt, idx, n, cs, ct, part, done);
@@ -485,17 +491,19 @@ static int shard_sums(icp_ctx *ctx, const double *src, const double *tgt, const 
         *nb_out = nb;
         return ICP_OK;
     }
-    return reduce_to(ctx, nb, sums_out, kSumSlots, 0, done);
+    return reduce_to(ctx, part, nb, sums_out, kSumSlots, 0, done);
 }
 
-static int column_sums(icp_ctx *ctx, const double *a, int64_t n, int dim, double *out, int mean) {
-    if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
+static int column_sums(icp_ctx *ctx, const double *a, int64_t n, int dim, double *out, int mean, double *part = nullptr) {
+    if (!part) {
+        if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
+        part = (double *)ctx->partials.ptr;
+    }
     const int nb = nblocks_for(n);
-    double *part = (double *)ctx->partials.ptr;
     if (dim == 3) hipLaunchKernelGGL(column_sums_kernel<3>, dim3(nb), dim3(RB), 0, ctx->stream, a, n, part);
     else hipLaunchKernelGGL(column_sums_kernel<2>, dim3(nb), dim3(RB), 0, ctx->stream, a, n, part);
     ICP_HIP_CHECK(hipGetLastError());
-    return reduce_to(ctx, nb, out, dim, mean ? dim : 0, nullptr);
+    return reduce_to(ctx, part, nb, out, dim, mean ? dim : 0, nullptr);
 }
 
 static int kabsch_solve(icp_ctx *ctx, const double *sums, int dim, const double *cs, const double *ct, double *R,
@@ -533,7 +541,7 @@ static int apply_err(icp_ctx *ctx, int mode, const double *src, const double *tg
         return ICP_OK;
     }
     // only slot 0 of each partial row is written in this mode
-    return reduce_to(ctx, nb, err_out, 1, 0, done);
+    return reduce_to(ctx, part, nb, err_out, 1, 0, done);
 }
 
 }  // namespace icp
@@ -583,6 +591,48 @@ extern "C" int icp_find_transform(icp_ctx *ctx, const double *src, const double 
     if (int rc = column_sums(ctx, src, n, dim, cs, 1)) return rc;
     if (int rc = column_sums(ctx, nn, n, dim, ct, 1)) return rc;
     if (int rc = shard_sums(ctx, src, nn, nullptr, n, dim, cs, ct, sums, nullptr)) return rc;
+    return kabsch_solve(ctx, sums, dim, cs, ct, R_out_dev, t_out_dev, nullptr);
+}
+
+// ---- the entry point that allocates nothing (include/icp_hip.h: icp_find_transform_noalloc) ----
+// Block-partial rows + the small state of one FindTransform, as a file-scope device array: every GPU the library runs
+// on holds its own copy (66 048 bytes) until the process ends.  `scratch` is a host-side stand-in for the symbol, not
+// a device address: host code only ever uses the per-device pointer that noalloc_init() obtains.
+constexpr int kNoallocStateDoubles = 64;  // [cs 16 | ct 16 | sums 16 | spare 16]
+constexpr size_t kNoallocDoubles = (size_t)icp::kRowBlocksMax * icp::kSumSlots + kNoallocStateDoubles;
+static __device__ __align__(256) double scratch[kNoallocDoubles];
+
+namespace icp {
+// called by icp_ctx_create with the context's device current: each device has its own copy of the array
+int noalloc_init(icp_ctx *ctx) {
+    void *p = nullptr;
+    ICP_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    ctx->noalloc_scratch = (double *)p;
+    return ICP_OK;
+}
+}  // namespace icp
+
+extern "C" int icp_find_transform_noalloc(icp_ctx *ctx, const double *src, const double *nn, int64_t n, int dim,
+                                          double *R_out_dev, double *t_out_dev) {
+    ICP_COMMON_ARGS(ctx, dim);
+    ICP_REQUIRE(src && nn && R_out_dev && t_out_dev && n > 0, "bad argument");
+    if (n > ICP_NOALLOC_MAX_ROWS) {
+        set_error("icp_find_transform_noalloc: n = %lld exceeds the limit of %lld rows", (long long)n,
+                  (long long)ICP_NOALLOC_MAX_ROWS);
+        return ICP_ERR_UNSUPPORTED;
+    }
+    if (!ctx->noalloc_scratch) {
+        set_error("icp_find_transform_noalloc: the context holds no address of the device scratch array");
+        return ICP_ERR_HIP;
+    }
+    // same kernels, same launch shapes and same summation trees as icp_find_transform: identical bits.  Every block
+    // writes its whole partial row before the single-block reductions read it, so nothing has to start at zero.
+    double *part = ctx->noalloc_scratch;
+    double *base = part + (size_t)kRowBlocksMax * kSumSlots;
+    double *cs = base, *ct = base + 16, *sums = base + 32;
+    if (int rc = column_sums(ctx, src, n, dim, cs, 1, part)) return rc;
+    if (int rc = column_sums(ctx, nn, n, dim, ct, 1, part)) return rc;
+    if (int rc = shard_sums(ctx, src, nn, nullptr, n, dim, cs, ct, sums, nullptr, nullptr, part)) return rc;
     return kabsch_solve(ctx, sums, dim, cs, ct, R_out_dev, t_out_dev, nullptr);
 }
 

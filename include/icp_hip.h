@@ -110,6 +110,17 @@ int icp_distance_sum(icp_ctx *ctx, const double *a, const double *b, int64_t n, 
 int icp_find_transform(icp_ctx *ctx, const double *src, const double *nn, int64_t n, int dim,
                        double *R_out_dev, double *t_out_dev);
 
+/* FindTransform for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments, same kernels and the
+ * same bits as icp_find_transform, but the block-partial rows and the small state live in a file-scope
+ * device array of 66 048 bytes that every GPU holds from library load to process end: this call performs no
+ * hipMalloc / hipFree and no allocating library routine.  Limit: n <= ICP_NOALLOC_MAX_ROWS, larger inputs
+ * are refused with ICP_ERR_UNSUPPORTED.  All calls on one GPU (from any context) share that array: calls
+ * that overlap on one GPU (different streams or threads) race; serialise them. */
+#define ICP_NOALLOC_MAX_ROWS ((int64_t)1 << 27)
+int icp_find_transform_noalloc(icp_ctx *ctx, const double *src, const double *nn, int64_t n, int dim,
+                               double *R_out_dev, double *t_out_dev);
+
 /* ss = src R + t: icp_3d.py:113 */
 int icp_apply_transform(icp_ctx *ctx, const double *src, int64_t n, int dim, const double *R_dev,
                         const double *t_dev, double *out);
