@@ -167,16 +167,19 @@ class Context:
 
     # -- buffers ---------------------------------------------------------
     def to_dev(self, a, dtype=None):
-        """numpy array / torch tensor -> contiguous tensor on this device."""
+        """numpy array / torch tensor -> contiguous tensor of `dtype` (default float64: every kernel of the
+        library computes in fp64, like the reference's numpy arrays) ON THIS CONTEXT'S DEVICE.  A tensor of
+        another dtype (torch's default float32 included) or on another GPU is converted / moved, never handed
+        over as it is: the C-ABI takes raw pointers and would read it as fp64 on this device."""
         torch = self.torch
+        want = torch.float64 if dtype is None else dtype
         if isinstance(a, torch.Tensor):
+            dev = torch.device("cuda", self.device)
             t = a
-            if dtype is not None and t.dtype != dtype:
-                t = t.to(dtype)
-            if not t.is_cuda:
-                t = t.cuda(self.device)
+            if t.dtype != want or t.device != dev:
+                t = t.to(device=dev, dtype=want)
             return t.contiguous()
-        arr = np.ascontiguousarray(a, dtype=np.float64 if dtype in (None, torch.float64) else np.int32)
+        arr = np.ascontiguousarray(a, dtype=np.float64 if want == torch.float64 else np.int32)
         return torch.from_numpy(arr).cuda(self.device)
 
     def empty(self, shape, dtype=None):

@@ -59,6 +59,7 @@ struct icp_ctx {
     // default stream (which `stream` may be), so they are captured and launched on this one
     hipStream_t side = nullptr;
     hipEvent_t side_ev = nullptr;
+    hipEvent_t order_ev = nullptr;  // icp_ctx_set_stream: orders a new stream after the work queued on the previous one
     // this device's address of kabsch.hip's file-scope scratch array (icp_find_transform_noalloc)
     double *noalloc_scratch = nullptr;
 };

@@ -76,13 +76,24 @@ extern "C" int icp_ctx_destroy(icp_ctx *ctx) {
         (void)hipStreamDestroy(ctx->side);
     }
     if (ctx->side_ev) (void)hipEventDestroy(ctx->side_ev);
+    if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
     delete ctx;
     return ICP_OK;
 }
 
+// The context's scratch buffers (block partials, RigidState, work arrays, the deferred-query list and its
+// counters) assume ONE stream of execution.  When the caller moves the context to another stream, work already
+// queued on the old stream may still be using them, so the new stream is made to wait for it (an event, no host
+// synchronisation): calls issued under different streams are then ordered like calls on one stream.
 extern "C" int icp_ctx_set_stream(icp_ctx *ctx, icp_stream stream) {
     ICP_REQUIRE(ctx != nullptr, "null context");
-    ctx->stream = (hipStream_t)stream;
+    hipStream_t next = (hipStream_t)stream;
+    if (next == ctx->stream) return ICP_OK;
+    ICP_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->order_ev) ICP_HIP_CHECK(hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
+    ICP_HIP_CHECK(hipEventRecord(ctx->order_ev, ctx->stream));
+    ICP_HIP_CHECK(hipStreamWaitEvent(next, ctx->order_ev, 0));
+    ctx->stream = next;
     return ICP_OK;
 }
 

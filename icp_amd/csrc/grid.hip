@@ -799,7 +799,7 @@ __global__ __launch_bounds__(GB) void grid_knn_kernel(const double *__restrict__
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        idx_out[t * K + k] = id[k];
+        idx_out[t * K + k] = id[k] == 0x7fffffff ? -1 : id[k];
         dist_out[t * K + k] = key[k];
     }
 }

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NB) void knn_rows_kernel(const double *__restrict__
     if (qi < nq) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            idx_out[qi * K + k] = id[k];
+            idx_out[qi * K + k] = id[k] == 0x7fffffff ? -1 : id[k];  // unfilled slot (fewer than K comparable points)
             dist_out[qi * K + k] = key[k];
         }
     }
@@ -2163,7 +2163,8 @@ extern "C" int nicp_knn(icp_ctx *ctx, const double *v, int64_t n, int dim, const
     ICP_REQUIRE(ctx && v && q && idx_out && dist_out, "null pointer");
     ICP_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
     ICP_REQUIRE(n > 0 && nq >= 0 && (k == 6 || k == 8), "k must be 6 or 8 (use 8 and truncate for other k <= 8)");
-    ICP_REQUIRE(n >= k, "fewer points than k (nicp3d.cpp:130-135 pops an empty heap; refused here)");
+    // n < k: the n points come back in order and the remaining slots hold index -1 / distance +inf (the reference's
+    // heap returns its size n and then pops past the empty heap, nicp3d.cpp:130-135; numpy's argsort returns n entries)
     if (nq == 0) return ICP_OK;
     ICP_HIP_CHECK(hipSetDevice(ctx->device));
     {   // large point sets: the exact grid search (same keys, same tie rule); ICP_KNN_GRID_MIN moves the switch

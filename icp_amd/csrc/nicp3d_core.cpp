@@ -32,7 +32,47 @@ nicp3d::nicp3d(int device, bool reference_compat) : compat_(reference_compat) {
 
 nicp3d::~nicp3d() {
     releaseGraph();
+    dropCache(cacheA_);
+    dropCache(cacheB_);
+    if (scratch_) icp_free(ctx_, scratch_);
     icp_ctx_destroy(ctx_);
+}
+
+void nicp3d::dropCache(DevCache &slot) {
+    if (slot.dev) icp_free(ctx_, slot.dev);
+    slot = DevCache();
+}
+
+// FNV-1a over the 64-bit words of the array: ~1 ns per point, against ~1 us of PCIe per kilobyte saved
+static uint64_t content_hash(const double *p, size_t count) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < count; ++i) {
+        uint64_t w;
+        std::memcpy(&w, p + i, sizeof(w));
+        h = (h ^ w) * 1099511628211ull;
+    }
+    return h;
+}
+
+const double *nicp3d::cached(DevCache &slot, const Array2D<double> &a) {
+    const size_t count = (size_t)a.dim1() * a.dim2(), bytes = count * sizeof(double);
+    const uint64_t h = content_hash(a.data(), count);
+    if (slot.dev && slot.host == a.data() && slot.rows == a.dim1() && slot.cols == a.dim2() && slot.hash == h)
+        return (const double *)slot.dev;
+    if (slot.cap < bytes) {
+        if (slot.dev) icp_free(ctx_, slot.dev);
+        slot.dev = nullptr;
+        slot.cap = 0;
+        check(icp_malloc(ctx_, bytes, &slot.dev), "icp_malloc");
+        slot.cap = bytes;
+    }
+    check(icp_memcpy_h2d(ctx_, slot.dev, a.data(), bytes), "h2d");
+    ++uploads_;
+    slot.host = a.data();
+    slot.rows = a.dim1();
+    slot.cols = a.dim2();
+    slot.hash = h;
+    return (const double *)slot.dev;
 }
 
 void nicp3d::releaseGraph() {
@@ -47,21 +87,25 @@ void nicp3d::check(int rc, const char *what) {
 }
 
 // nicp3d.cpp:100-137
+// Like the reference, a dataset with fewer than k points yields its n points (the heap size is returned; the
+// reference then pops past the empty heap, nicp3d.cpp:130-135 -- here the remaining slots hold -1 / +inf).
 int nicp3d::KNN(const Array2D<double> &dataset, const double *pt, int k, int *idx, double *dist) {
     if (k > 8 || k < 1) throw std::invalid_argument("KNN: k must be in 1..8");
     const int kk = k <= 6 ? 6 : 8, n = dataset.dim1(), dim = dataset.dim2();
-    DevBuf dv(ctx_, sizeof(double) * n * dim), dq(ctx_, sizeof(double) * dim), di(ctx_, sizeof(int32_t) * kk),
-        dd(ctx_, sizeof(double) * kk);
-    check(icp_memcpy_h2d(ctx_, dv.p, dataset.data(), sizeof(double) * n * dim), "h2d");
-    check(icp_memcpy_h2d(ctx_, dq.p, pt, sizeof(double) * dim), "h2d");
-    check(nicp_knn(ctx_, dv.as<double>(), n, dim, dq.as<double>(), 1, kk, di.as<int32_t>(), dd.as<double>()), "nicp_knn");
-    int32_t hi[8];
-    double hd[8];
-    check(icp_memcpy_d2h(ctx_, hi, di.p, sizeof(int32_t) * kk), "d2h");
-    check(icp_memcpy_d2h(ctx_, hd, dd.p, sizeof(double) * kk), "d2h");
+    if (n < 1) return 0;
+    const double *dv = cached(cacheA_, dataset);
+    // scratch block: [query 3 doubles | dist 8 doubles | idx 8 int32]
+    if (!scratch_) check(icp_malloc(ctx_, 256, &scratch_), "icp_malloc");
+    double *dq = (double *)scratch_, *dd = dq + 4;
+    int32_t *di = (int32_t *)(dq + 12);
+    check(icp_memcpy_h2d(ctx_, dq, pt, sizeof(double) * dim), "h2d");
+    check(nicp_knn(ctx_, dv, n, dim, dq, 1, kk, di, dd), "nicp_knn");
+    double back[12];  // dist (8 doubles) and idx (8 int32 = 4 doubles) in one copy
+    check(icp_memcpy_d2h(ctx_, back, dd, sizeof(back)), "d2h");
+    const int32_t *hi = (const int32_t *)(back + 8);
     for (int i = 0; i < k; ++i) {
         idx[i] = hi[i];
-        dist[i] = hd[i];
+        dist[i] = back[i];
     }
     return k < n ? k : n;
 }
@@ -69,17 +113,17 @@ int nicp3d::KNN(const Array2D<double> &dataset, const double *pt, int k, int *id
 // nicp3d.cpp:142-164 (compares sqrt distances; Q12)
 int nicp3d::Closest(const Array2D<double> &dataset, const double *pt, double *minDist) {
     const int n = dataset.dim1(), dim = dataset.dim2();
-    DevBuf dv(ctx_, sizeof(double) * n * dim), dq(ctx_, sizeof(double) * dim), di(ctx_, sizeof(int32_t)), dd(ctx_, sizeof(double));
-    check(icp_memcpy_h2d(ctx_, dv.p, dataset.data(), sizeof(double) * n * dim), "h2d");
-    check(icp_memcpy_h2d(ctx_, dq.p, pt, sizeof(double) * dim), "h2d");
-    check(icp_closest(ctx_, dq.as<double>(), 1, dv.as<double>(), n, dim, compat_ ? ICP_COMPARE_SQRT : 0u, di.as<int32_t>(),
-                      dd.as<double>()),
-          "icp_closest");
+    const double *dv = cached(cacheA_, dataset);
+    if (!scratch_) check(icp_malloc(ctx_, 256, &scratch_), "icp_malloc");
+    double *dq = (double *)scratch_, *dd = dq + 4;
+    int32_t *di = (int32_t *)(dq + 12);
+    check(icp_memcpy_h2d(ctx_, dq, pt, sizeof(double) * dim), "h2d");
+    check(icp_closest(ctx_, dq, 1, dv, n, dim, compat_ ? ICP_COMPARE_SQRT : 0u, di, dd), "icp_closest");
+    double back[9];  // d2 at [0], the index in the first int32 of [8]
+    check(icp_memcpy_d2h(ctx_, back, dd, sizeof(back)), "d2h");
     int32_t i;
-    double d2;
-    check(icp_memcpy_d2h(ctx_, &i, di.p, sizeof(i)), "d2h");
-    check(icp_memcpy_d2h(ctx_, &d2, dd.p, sizeof(d2)), "d2h");
-    if (minDist) *minDist = std::sqrt(d2);
+    std::memcpy(&i, back + 8, sizeof(i));
+    if (minDist) *minDist = std::sqrt(back[0]);
     return i;
 }
 
@@ -94,6 +138,8 @@ void nicp3d::Initialise(const Array2D<double> &vert) {
         params[i * 12 + 8] = 1.0;
     }
     if (compat_) params[params.dim1() - 1] = 2.0;  // nicp3d.cpp:194 (debug translation, Q9)
+    dropCache(cacheA_);
+    dropCache(cacheB_);
     DevBuf dv(ctx_, sizeof(double) * n * 3), dn(ctx_, sizeof(int32_t) * n * NUM_NN), dw(ctx_, sizeof(double) * n * NUM_NN);
     check(icp_memcpy_h2d(ctx_, dv.p, vert.data(), sizeof(double) * n * 3), "h2d");
     check(nicp_knn_weights(ctx_, dv.as<double>(), n, 3, NUM_NN, dn.as<int32_t>(), dw.as<double>()), "nicp_knn_weights");
@@ -109,13 +155,10 @@ void nicp3d::Initialise(const Array2D<double> &vert) {
 void nicp3d::Match(const Array2D<double> &source, const Array2D<double> &target, Array2D<double> &matchset) {
     const int n = source.dim1(), m = target.dim1(), dim = source.dim2();
     matchset = Array2D<double>(n, dim);
-    DevBuf ds(ctx_, sizeof(double) * n * dim), dt(ctx_, sizeof(double) * m * dim), di(ctx_, sizeof(int32_t) * n),
-        dn(ctx_, sizeof(double) * n * dim);
-    check(icp_memcpy_h2d(ctx_, ds.p, source.data(), sizeof(double) * n * dim), "h2d");
-    check(icp_memcpy_h2d(ctx_, dt.p, target.data(), sizeof(double) * m * dim), "h2d");
-    check(icp_closest(ctx_, ds.as<double>(), n, dt.as<double>(), m, dim, compat_ ? ICP_COMPARE_SQRT : 0u, di.as<int32_t>(), nullptr),
-          "icp_closest");
-    check(icp_gather_points(ctx_, dt.as<double>(), di.as<int32_t>(), n, dim, dn.as<double>()), "icp_gather_points");
+    DevBuf di(ctx_, sizeof(int32_t) * n), dn(ctx_, sizeof(double) * n * dim);
+    const double *dt = cached(cacheA_, target), *ds = cached(cacheB_, source);
+    check(icp_closest(ctx_, ds, n, dt, m, dim, compat_ ? ICP_COMPARE_SQRT : 0u, di.as<int32_t>(), nullptr), "icp_closest");
+    check(icp_gather_points(ctx_, dt, di.as<int32_t>(), n, dim, dn.as<double>()), "icp_gather_points");
     check(icp_memcpy_d2h(ctx_, matchset.data(), dn.p, sizeof(double) * n * dim), "d2h");
 }
 

@@ -93,10 +93,29 @@ public:
     Array2D<double> landmarkPos;
     double cLand = 0.0;
     std::string lastError() const;
+    // how many times KNN / Closest / Match uploaded a whole dataset since construction (they keep the device
+    // copy of the last dataset / target and re-upload only when the host array changed)
+    long datasetUploads() const { return uploads_; }
 
 private:
     void check(int rc, const char *what);
     void releaseGraph();
+    // Device copy of a host array, kept between calls: the reference's per-point methods receive the same
+    // ref-counted Array2D on every call (nicp3d.cpp:201,266) and pay nothing for it; re-uploading N points per
+    // QUERY would cost O(N) PCIe traffic per call here.  A slot is reused while the host pointer, the shape and a
+    // 64-bit hash of the contents are unchanged; Initialise drops both slots.
+    struct DevCache {
+        const void *host = nullptr;
+        int rows = 0, cols = 0;
+        uint64_t hash = 0;
+        void *dev = nullptr;
+        size_t cap = 0;
+    };
+    const double *cached(DevCache &slot, const Array2D<double> &a);
+    void dropCache(DevCache &slot);
+    DevCache cacheA_, cacheB_;  // A: KNN / Closest dataset, Match target; B: Match source
+    void *scratch_ = nullptr;   // one small device block for the per-call query / result of KNN and Closest
+    long uploads_ = 0;
     icp_ctx *ctx_ = nullptr;
     nicp_graph *graph_ = nullptr;
     bool compat_;

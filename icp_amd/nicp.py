@@ -6,6 +6,7 @@ device, still answers `w[j, i]`, `.sum(0)` and `.toarray()` for small N, and own
 mesh-graph handle the Jacobian products need.
 """
 import ctypes
+import hashlib
 
 import numpy as np
 
@@ -62,24 +63,31 @@ class SparseWeights:
 
     # -- graph handle -----------------------------------------------------
     def graph(self, edges=None):
-        """nicp_graph for these weights + edge list (cached per edge array identity)."""
+        """nicp_graph for these weights + edge list.  numpy edge lists are cached by content.  A device address
+        alone is no identity (the caching allocator hands it to the next tensor; tensors are edited in place), so
+        tensors are cached by (address, shape, version counter) and the entry HOLDS the tensor: its storage cannot
+        be recycled while the entry lives, and an in-place edit bumps the version and builds a new graph."""
         ctx = self.ctx
+        keep = None
         if edges is None:
             e_dev, key = None, None
+        elif hasattr(edges, "is_cuda"):
+            keep = edges
+            key = ("tensor", edges.data_ptr(), tuple(edges.shape), str(edges.dtype), str(edges.device), edges._version)
+            e_dev = None
         else:
-            if not hasattr(edges, "is_cuda"):
-                edges = np.ascontiguousarray(np.asarray(edges).astype(np.int32))   # Q11: the reference holds floats
-                key = edges.tobytes()
-            else:
-                key = edges.data_ptr()
-            e_dev = ctx.to_dev(edges, ctx.torch.int32)
+            edges = np.ascontiguousarray(np.asarray(edges).astype(np.int32))   # Q11: the reference holds floats
+            key = ("numpy", edges.shape, hashlib.sha1(edges.tobytes()).digest())
+            e_dev = None
         if key not in self._graphs:
+            if edges is not None:
+                e_dev = ctx.to_dev(edges, ctx.torch.int32)
             h = ctypes.c_void_p()
             ne = 0 if e_dev is None else e_dev.shape[0]
             ctx.call("nicp_graph_create", ptr(self.nbr), ptr(self.wt), self.nbr.shape[0], self.nbr.shape[1],
                      ptr(e_dev), ne, self.dim, ctypes.byref(h))
-            self._graphs[key] = (h, ne)
-        return self._graphs[key]
+            self._graphs[key] = (h, ne, keep)
+        return self._graphs[key][:2]
 
     # -- extended energy (SURVEY.md 8f n4; not in the reference) -----------
     def set_weights(self, edges, fit_w=None, rigid_w=None, edge_w=None):
@@ -123,7 +131,7 @@ class SparseWeights:
 
     def __del__(self):
         try:
-            for h, _ in self._graphs.values():
+            for h, _, _ in self._graphs.values():
                 self.ctx.lib.nicp_graph_destroy(self.ctx.handle, h)
             self._graphs = {}
         except Exception:
@@ -138,11 +146,12 @@ def knn(dset, queries, k, ctx=None):
     if k > 8:
         raise ValueError("KNN on the GPU supports k <= 8 (the reference uses num_nn+2 = 6)")
     kk = 6 if k <= 6 else 8
-    if v.shape[0] < kk:
-        raise ValueError("KNN needs at least %d points" % kk)
+    if v.shape[0] < 1:
+        raise ValueError("KNN over an empty point set")
     idx = ctx.empty((q.shape[0], kk), ctx.torch.int32)
     dist = ctx.empty((q.shape[0], kk))
     ctx.call("nicp_knn", ptr(v), v.shape[0], v.shape[1], ptr(q), q.shape[0], kk, ptr(idx), ptr(dist))
+    k = min(k, v.shape[0])      # fewer points than k: np.argsort(...)[0:k] returns them all (nicp_3d.py:56)
     return idx[:, :k].contiguous(), dist[:, :k].contiguous()
 
 

@@ -15,7 +15,12 @@
  *    row-major [rows, dim] (AoS), dim in {2,3}; row-vector convention p' = p R + t.
  *  - work is enqueued on the context's stream (icp_ctx_set_stream) and is
  *    asynchronous unless stated; calls on one context must be serialised by the
- *    caller; contexts are independent.
+ *    caller (one host thread at a time); contexts are independent.  A context's
+ *    scratch state assumes one stream of execution: icp_ctx_set_stream with a
+ *    different stream makes the new stream wait (by an event, without blocking the
+ *    host) for everything the context queued on the previous one, so calls issued
+ *    under different streams run in issue order.  Use one context per stream for
+ *    work that should overlap.
  *  - the library frees nothing it did not allocate.
  */
 #ifndef ICP_HIP_H
@@ -176,7 +181,8 @@ enum {
 
 /* KNN: nicp_3d.py:53-57 / nicp3d.cpp:100-137.  For every row of q[nq,dim] the k smallest
  * Euclidean distances (fp64, with sqrt) to the rows of v[n,dim], ascending, ties to the lower
- * index; k must be 6 or 8.  idx_out[nq,k] int32, dist_out[nq,k]. */
+ * index; k must be 6 or 8.  idx_out[nq,k] int32, dist_out[nq,k].  With fewer than k comparable points
+ * (n < k, or NaN coordinates) the unfilled slots hold index -1 and distance +inf. */
 int nicp_knn(icp_ctx *ctx, const double *v, int64_t n, int dim, const double *q, int64_t nq, int k,
              int32_t *idx_out, double *dist_out);
 

@@ -557,6 +557,72 @@ def nicp(P, nbr, wt, source, edges, target, tol, run, c=(C_FIT, C_RIGID, C_SMOOT
     return deform(P, nbr, wt, source), P, tuple(c)
 
 
+def lm_dense(P0, nbr, wt, source, edges, nn, c=(C_FIT, C_RIGID, C_SMOOTH), compat=True, steps=1,
+             lambda0=1e-3, ftol=1.49012e-8, xtol=1.49012e-8, trace=None):
+    """Dense twin of the PRODUCT's Levenberg-Marquardt loop (icp_amd/csrc/nicp.hip, solve_impl), on this
+    file's min_func / d_min_func -- NOT a restatement of MINPACK.  Test infrastructure: what the reference
+    determines in compat mode is the pair (MinFunc, D_MinFunc), pinned to it at 1e-12 by the golden
+    fixtures; given that pair, every LM step `(J^T J + lam D^2) delta = -J^T r` with MINPACK's column
+    scaling D = max-so-far column norm of J (lmder.f, mode 1) is a determinate quantity, which the
+    leastsq END POINT in compat mode is not (oracle/study_compat_sensitivity.py).  The GPU solve with a
+    tight CG tolerance must reproduce these steps to 1e-6 (tests/test_gpu_nicp.py).
+
+    Runs `steps` accepted steps (or stops on lmder's ftol / xtol tests) and returns
+    (P, info dict(err0, err, nfev, lm_iters, info, lams)).  Acceptance: gain ratio > 1e-4 (lmder.f);
+    damping: Nielsen's update on acceptance, lam *= nu, nu *= 2 on rejection."""
+    x = np.array(P0, dtype=np.float64)
+    f = lambda p: min_func(p, nbr, wt, source, edges, nn, c, compat)
+    Jf = lambda p: d_min_func(p, nbr, wt, source, edges, nn, c, compat)
+    r = f(x)
+    f2 = float(r @ r)
+    out = dict(err0=f2, nfev=1, lm_iters=0, info=0, lams=[])
+    lam, nu = lambda0, 2.0
+    d2 = None
+    for it in range(steps):
+        out["lm_iters"] = it + 1
+        J = Jf(x)
+        grad = J.T @ r
+        col2 = (J * J).sum(0)
+        d2 = np.where(col2 > 0, col2, 1.0) if d2 is None else np.maximum(d2, col2)
+        H = J.T @ J
+        accepted = False
+        while not accepted and not out["info"]:
+            delta = np.linalg.solve(H + lam * np.diag(d2), -grad)
+            xt = x + delta
+            rt = f(xt)
+            f2t = float(rt @ rt)
+            out["nfev"] += 1
+            dn2, dg, xn2 = float((delta * delta * d2).sum()), float(delta @ grad), float((x * x * d2).sum())
+            pred, actred = lam * dn2 - dg, f2 - f2t
+            ratio = actred / pred if pred > 0 else (1.0 if actred > 0 else -1.0)
+            if trace is not None:
+                trace.append(dict(it=it, lam=lam, f2=f2, f2t=f2t, ratio=ratio, delta=delta.copy()))
+            if np.isfinite(f2t) and ratio > 1e-4:
+                out["lams"].append(lam)
+                x, r, accepted = xt, rt, True
+                t = 2 * ratio - 1
+                lam *= max(1.0 / 3.0, 1 - t * t * t)
+                nu = 2.0
+                t_f = abs(actred) <= ftol * f2 and pred <= ftol * f2 and 0.5 * ratio <= 1
+                t_x = np.sqrt(dn2) <= xtol * np.sqrt(xn2)
+                f2 = f2t
+                if t_f:
+                    out["info"] = 1
+                if t_x:
+                    out["info"] = 3 if out["info"] == 1 else 2
+            else:
+                lam *= nu
+                nu *= 2.0
+                if np.sqrt(dn2) <= xtol * np.sqrt(xn2) or lam > 1e30:
+                    out["info"] = 2
+        if out["info"]:
+            break
+    if not out["info"]:
+        out["info"] = 5
+    out["err"] = f2
+    return x, out
+
+
 # --------------------------------------------------------------------------
 # seeded synthetic workloads (SURVEY.md section 8d) -- shared by tests and bench
 # --------------------------------------------------------------------------

@@ -93,6 +93,77 @@ def test_nicp3d_cli_landmarks(tmp_path):
     assert bad.returncode != 0 and "COMPAT" in bad.stderr
 
 
+def test_nicp3d_small_methods_and_dataset_cache(tmp_path):
+    """RotMatrix / D_RotMatrix (nicp3d.cpp:384-422) against the reference-generated golden R, dR; PtoAB
+    (nicp3d.cpp:376-379) with quirk Q8 (every vertex gets vertex 0's A, its own b) and without; 1 000 Closest +
+    1 000 KNN calls on one 100 000-point dataset upload it ONCE (the C++ host keeps the device copy; an edit of
+    the host array is noticed); KNN on fewer points than k returns them all like the reference's heap."""
+    from icp_amd import rigid, nicp
+    g = golden("nicp_init_60")
+    rng = np.random.default_rng(77)
+    data = rng.standard_normal((100000, 3))
+    q = np.concatenate([data[:500] + 1e-3 * rng.standard_normal((500, 3)), rng.standard_normal((500, 3)) * 2])
+    write_obj(tmp_path / "d.obj", data, [])
+    write_obj(tmp_path / "q.obj", q, [])
+    data = read_obj_vertices(tmp_path / "d.obj")          # what the CLI parses (%.17g round-trips exactly)
+    q = read_obj_vertices(tmp_path / "q.obj")
+    for fixed in (False, True):
+        out = subprocess.run([CLI, "--selftest", str(tmp_path / "d.obj"), str(tmp_path / "q.obj")] + (["--fixed"] if fixed else []),
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr
+        rows = {}
+        for ln in out.stdout.splitlines():
+            parts = ln.split()
+            rows.setdefault(parts[0], []).append(parts[1:])
+        assert np.array_equal(np.array(rows["R"][0], float).reshape(3, 3), g["R"])
+        for k, tag in enumerate(("dRx", "dRy", "dRz")):
+            assert np.array_equal(np.array(rows[tag][0], float).reshape(3, 3), g["dR"][k])
+        params = np.arange(5 * 12 + 6) / 7.0
+        for row in rows["PtoAB"]:
+            i, vals = int(row[0]), np.array(row[1:], float)
+            src = i if fixed else 0                          # Q8
+            assert np.array_equal(vals[:9], params[src * 12:src * 12 + 9])
+            assert np.array_equal(vals[9:], params[i * 12 + 9:i * 12 + 12])
+        idx, d2 = rigid.closest_indices(q, data, compare_sqrt=not fixed, want_d2=True)
+        got = np.array(rows["closest"], float)
+        assert np.array_equal(got[:, 1].astype(int), idx.cpu().numpy())
+        assert np.array_equal(got[:, 2], np.sqrt(d2.cpu().numpy()))
+        ki, kd = nicp.knn(data, q, 6)
+        gk = np.array(rows["knn"], float)
+        assert np.array_equal(gk[:, 2:8].astype(int), ki.cpu().numpy()) and np.array_equal(gk[:, 8:14], kd.cpu().numpy())
+        assert (gk[:, 1] == 6).all()
+        assert rows["uploads"][0] == ["1"]                  # 2 000 per-point calls, one H2D of the 2.4 MB dataset
+        small = rows["knn_small"][0]
+        oi = np.argsort(np.sqrt(((data[:4] - q[0]) ** 2).sum(1)), kind="stable")
+        assert int(small[0]) == 4 and [int(x) for x in small[1:7]] == list(oi) + [-1, -1]
+        np.testing.assert_allclose(np.array(small[7:11], float), np.sort(np.sqrt(((data[:4] - q[0]) ** 2).sum(1))), rtol=1e-15)
+        edit = rows["closest_after_edit"][0]
+        assert int(edit[0]) == 0 and float(edit[1]) == 0.0 and int(edit[3]) == 3   # small set, then the edited set
+
+
+def test_python_small_functions_and_small_knn():
+    """a8 / a9 of SURVEY.md 8a for the Python host: D_RotMatrix vs the reference-generated golden dR, PtoAB
+    views (nicp_3d.py:171-175); KNN with fewer points than k returns them all (nicp_3d.py:53-57)."""
+    from icp_amd import nicp_3d
+    g = golden("nicp_init_60")
+    dR = nicp_3d.D_RotMatrix(0.3, -0.4, 0.5)
+    assert isinstance(dR, tuple) and len(dR) == 3
+    for k in range(3):
+        assert np.array_equal(dR[k], g["dR"][k])
+    assert np.array_equal(nicp_3d.RotMatrix(0.3, -0.4, 0.5), g["R"])
+    P = np.arange(5 * 12 + 6) / 7.0
+    A, b = nicp_3d.PtoAB(P, 3)
+    assert np.array_equal(A, P[36:45].reshape(3, 3)) and np.array_equal(b, P[45:48])
+    A[1, 2] = -1.0                                           # views into P like the reference's slices
+    assert P[36 + 5] == -1.0
+    oA, ob = orc.p_to_ab(P, 3)
+    assert np.array_equal(A, oA) and np.array_equal(b, ob)
+    pts = g["v"][:4]
+    idx, dist = nicp_3d.KNN(pts, g["v"][10], 6)
+    d = np.sqrt(((pts - g["v"][10]) ** 2).sum(1))
+    assert np.array_equal(idx, np.argsort(d, kind="stable")) and np.array_equal(dist, np.sort(d))
+
+
 def test_nicp_row_module():
     from icp_amd import nicp_row
     g = golden("nicp_row_20")
@@ -104,10 +175,16 @@ def test_nicp_row_module():
     np.testing.assert_allclose(nicp_row.MinFunc(g["P_rand"], w, v, edges, nn), g["r"], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(nicp_row.D_MinFunc(g["P_rand"], w, v, edges, nn), g["J"], rtol=1e-6, atol=1e-9)
     assert np.array_equal(nicp_row.Match(nicp_row.Deform(P0, w, v), g["tgt"]), nn)
-    # solve: energy no worse than the reference's leastsq result (compat Jacobian, Q7)
+    # solve: energy no worse than the reference's leastsq result (compat Jacobian, Q7; the fixture is what
+    # oracle/gen_golden.py produces in this container).  The end point itself is not determinate at 1e-6 --
+    # profiles/r2_compat_sensitivity.txt -- each LM step is (test_gpu_nicp.py::test_lm_steps_match_dense_solves).
     from icp_amd import nicp
     P, st = nicp.solve(P0, w, v, edges, nn, (0.1, 1000, 100), compat=True)
     assert st["err"] <= float(g["lsq_err"]) * (1 + 1e-6)
+    # (with Q7's unweighted b-columns the Jacobian is far from the residual's derivative: MINPACK's trust region
+    # collapses at a higher energy than the LM-CG loop reaches, the two end points are ~1e-2 apart in the vertices)
+    dd = nicp.deform(P, w, v).cpu().numpy()
+    print("nicp_row_20 compat: err", st["err"], "reference", float(g["lsq_err"]), "max |dd - ref|", np.abs(dd - g["lsq_deformed"]).max())
 
 
 def test_nicp_row_rt_module():

@@ -141,8 +141,12 @@ def test_solve_corrected_vs_leastsq(mods, name):
 def test_solve_compat_vs_golden(mods, name):
     """Reference-as-coded mode: the Jacobian is not the derivative of the residual (Q5/Q6), so
     MINPACK stops where its trust region collapses (ier=2) -- a path-dependent point no other
-    solver can hit exactly (DESIGN.md 'NICP solve parity').  Pinned here: the GPU solve reaches
-    an energy no worse than the reference's and deformed vertices within 1e-4 of it."""
+    solver can hit exactly (DESIGN.md 'NICP solve parity').  Measured floor: perturbing P0 by 1e-15 moves
+    scipy's OWN end point on these fixtures by 2e-5 ... 1.7e-3 (relative, deformed vertices) and its
+    energy by 4 % (oracle/study_compat_sensitivity.py -> profiles/r2_compat_sensitivity.txt), so 1e-6 of
+    that end point is not a meaningful bar.  What is determinate -- every LM step's linear solve -- is held
+    to 1e-6 by test_lm_steps_match_dense_solves.  Pinned here: the GPU solve reaches an energy no worse
+    than the reference's and deformed vertices within 1e-4 of it."""
     g = golden(name)
     v, edges, nn, P0 = g["v"], g["edges"], g["nn"], g["P0"]
     P, st = mods["nicp"].solve(P0, g["w"], v, edges, nn, C, compat=True)
@@ -150,6 +154,36 @@ def test_solve_compat_vs_golden(mods, name):
     print(name, "compat: leastsq err", float(g["lsq_err"]), "gpu", st, "max |dd-ref|", np.abs(dd - g["lsq_deformed"]).max())
     assert st["err"] <= float(g["lsq_err"]) * (1 + 1e-6)
     np.testing.assert_allclose(dd, g["lsq_deformed"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["nicp_step_24", "nicp_step_60", "nicp_row_20"])
+@pytest.mark.parametrize("compat", [True, False])
+@pytest.mark.parametrize("start", ["P0", "P_rand"])
+def test_lm_steps_match_dense_solves(mods, name, compat, start):
+    """What IS determinate in the reference-as-coded mode: given the pinned pair (MinFunc, D_MinFunc), each
+    Levenberg-Marquardt step  (J^T J + lam D^2) delta = -J^T r.  The GPU solve (matrix-free J, preconditioned
+    CG driven to 1e-13) must reproduce the dense numpy solves built from the oracle's J and r -- whose
+    operators are pinned to the reference at 1e-12 -- to 1e-6, in compat AND corrected mode, from the
+    reference's start P0 (R = I) and from a perturbed P (R != I: exercises Q6, rejected trials and the
+    damping updates).  A sign or slot error in a compat-only branch of jp / jtu / block_diag that still
+    lowered the energy would fail here."""
+    g = golden(name)
+    v, edges, nn, Ps = g["v"], g["edges"], g["nn"], g[start]
+    nbr, wt = sparse_from_dense(g["w"])
+    nic = mods["nicp"]
+    w = nic.SparseWeights(nbr, wt, v.shape[1])
+    for steps in (1, 4):
+        Pref, info = orc.lm_dense(Ps, nbr, wt, v, edges, nn, C, compat, steps=steps, ftol=0.0, xtol=0.0)
+        P, st = nic.solve(Ps, w, v, edges, nn, C, compat=compat,
+                          opts=dict(max_lm_iters=steps, cg_tol=1e-13, ftol=0.0, xtol=0.0))
+        d_ref, d_gpu = Pref - Ps, P.cpu().numpy() - Ps
+        print(name, compat, start, steps, "ref", {k: info[k] for k in ("err0", "err", "nfev")}, "gpu", st,
+              "max|d-dref|/max|dref|", np.abs(d_gpu - d_ref).max() / np.abs(d_ref).max())
+        assert st["nfev"] == info["nfev"] and st["lm_iters"] == info["lm_iters"]      # same accept / reject sequence
+        np.testing.assert_allclose(st["err0"], info["err0"], rtol=1e-9)
+        np.testing.assert_allclose(st["err"], info["err"], rtol=RTOL)
+        assert np.abs(d_gpu - d_ref).max() <= RTOL * np.abs(d_ref).max()
+        np.testing.assert_allclose(nic.deform(P, w, v).cpu().numpy(), orc.deform(Pref, nbr, wt, v), rtol=RTOL, atol=1e-9)
 
 
 def test_nicp_outer_loop(mods):

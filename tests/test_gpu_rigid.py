@@ -126,6 +126,62 @@ def test_empty_and_errors(api):
         api["icp_3d"].ICP(np.zeros((3, 3)), tgt, 0.1, 0)
 
 
+def test_float32_and_other_dtype_tensors_are_converted(api):
+    """a float32 CUDA tensor -- torch's default dtype -- must not reach the fp64 kernels as a raw
+    pointer.  Inputs of any dtype are converted to fp64 on the context's device: same result as the fp64 path on
+    the same (float32-representable) values."""
+    torch = api["torch"]
+    rng = np.random.default_rng(21)
+    src64 = rng.standard_normal((30000, 3)).astype(np.float32).astype(np.float64)
+    tgt64 = rng.standard_normal((5000, 3)).astype(np.float32).astype(np.float64)
+    ref = gpu_idx(api, src64, tgt64)
+    s32 = torch.from_numpy(src64.astype(np.float32)).cuda()
+    t32 = torch.from_numpy(tgt64.astype(np.float32)).cuda()
+    assert s32.dtype == torch.float32
+    assert np.array_equal(api["rigid"].closest_indices(s32, t32).cpu().numpy(), ref)
+    assert np.array_equal(api["rigid"].closest_indices(torch.from_numpy(src64.astype(np.float32)), t32.half().float()).cpu().numpy(),
+                          gpu_idx(api, src64, t32.half().double().cpu().numpy()))
+    T64 = api["icp_3d"].ICP(src64[:2000], tgt64, 0.1, 5)
+    T32 = api["icp_3d"].ICP(s32[:2000], t32, 0.1, 5)
+    assert T32.dtype == torch.float64 and np.array_equal(T32.cpu().numpy(), T64)
+    hint = torch.from_numpy(ref.astype(np.int64)).cuda()        # int64 hints are converted to the int32 the ABI takes
+    assert np.array_equal(api["rigid"].closest_indices(s32, t32, hint=hint, force_grid=True).cpu().numpy(), ref)
+
+
+def test_calls_under_two_streams_are_ordered(api):
+    """the context's scratch assumes one stream.  icp_rigid_run issued under stream A and,
+    without any host synchronisation, icp_closest under stream B share scratch buffers: the context orders B after
+    A (event wait in icp_ctx_set_stream), so both return what they return when run alone (correspondences and
+    squared distances bit for bit; the transform to 1e-13: the Morton sort of the source fills its cells through
+    atomic counters, so the order of the sums -- not their value beyond the last bits -- varies run to run)."""
+    torch = api["torch"]
+    rigid = api["rigid"]
+    src, tgt = orc.make_rigid_cloud(200000, seed=9)
+    rng = np.random.default_rng(10)
+    src2, tgt2 = rng.standard_normal((150000, 3)), rng.standard_normal((180000, 3))
+    sd, td, s2d, t2d = (torch.from_numpy(a).cuda() for a in (src, tgt, src2, tgt2))
+    alone_run = rigid.rigid_icp(sd, td, -np.inf, 6, want_idx=True)
+    torch.cuda.synchronize()
+    alone_T, alone_idx = alone_run["T"].clone(), alone_run["idx"].clone()
+    alone_c = rigid.closest_indices(s2d, t2d, want_d2=True)
+    torch.cuda.synchronize()
+    alone_c = (alone_c[0].clone(), alone_c[1].clone())
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        with torch.cuda.stream(a):
+            r = rigid.rigid_icp(sd, td, -np.inf, 6, want_idx=True)
+        with torch.cuda.stream(b):
+            c = rigid.closest_indices(s2d, t2d, want_d2=True)
+        with torch.cuda.stream(a):
+            r2 = rigid.rigid_icp(sd, td, -np.inf, 6, want_idx=True)
+        torch.cuda.synchronize()
+        for out in (r, r2):
+            assert torch.equal(out["idx"], alone_idx)
+            np.testing.assert_allclose(out["T"].cpu().numpy(), alone_T.cpu().numpy(), rtol=1e-13, atol=1e-13)
+        assert torch.equal(c[0], alone_c[0]) and torch.equal(c[1], alone_c[1])
+
+
 def test_distance_and_kabsch_golden(api):
     g = golden("kabsch_3d")
     R, t = api["icp_3d"].FindTransform(g["src"], g["nn"])
