@@ -3,7 +3,7 @@
 the decreasing stiffness schedule).  Not the driver's bench.py; prints one JSON line with
 outer-iterations/s and CG-iterations/s.
 
-  python benchmarks/nicp_bench.py [--nx 100 --ny 100] [--run 50] [--fixed] [--lm 100] [--cgtol 0]
+  python benchmarks/nicp_bench.py [--nx 100 --ny 100] [--run 50] [--fixed] [--lm 0] [--cgtol 0]
 """
 import argparse
 import json
@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--run", type=int, default=50)
     ap.add_argument("--tol", type=float, default=0.01)
     ap.add_argument("--fixed", action="store_true", help="self-consistent mode instead of reference_compat")
-    ap.add_argument("--lm", type=int, default=100)
+    ap.add_argument("--lm", type=int, default=0, help="cap on LM iterations per solve; 0 = leastsq's own limit only (100*(n+1) evaluations)")
     ap.add_argument("--cgtol", type=float, default=0.0, help="0 = the library default (automatic)")
     args = ap.parse_args()
     import torch
@@ -81,7 +81,11 @@ def main():
                       "cg_iters": cg, "cg_iters_per_s": cg / dt, "init_knn_weights_s": t_init,
                       "err_first": hist[0][0], "err_last": hist[-1][0], "final_c": list(c),
                       "max_abs_dev_from_target": float(res),
-                      "per_outer": [dict(err=h[0], c_rigid=h[1], lm=h[3]["lm_iters"], cg=h[3]["cg_iters"], info=h[3]["info"]) for h in hist]}))
+                      "lm_cap": args.lm if args.lm > 0 else "none (leastsq's maxfev = 100*(n+1) only)",
+                      "stopped_by": {name: sum(1 for h in hist if h[3]["info"] == code) for code, name in
+                                     ((1, "ftol"), (2, "xtol"), (3, "ftol+xtol"), (4, "gtol"), (5, "limit"))},
+                      "per_outer": [dict(err=h[0], c_rigid=h[1], lm=h[3]["lm_iters"], cg=h[3]["cg_iters"], nfev=h[3]["nfev"],
+                                         info=h[3]["info"]) for h in hist]}))
 
 
 if __name__ == "__main__":

@@ -2440,8 +2440,12 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
     }
     const bool compat = flags & 1u;
     const Dims d = dims_of(g);
-    nicp_solve_opts o = {1.49012e-8, 1.49012e-8, 0.0, 1e-3, 0.0, 100, 0};
+    nicp_solve_opts o = {1.49012e-8, 1.49012e-8, 0.0, 1e-3, 0.0, 0, 0};
     if (opts_in) o = *opts_in;
+    // leastsq's own limit (nicp_3d.py:351 passes no maxfev: MINPACK's default with an analytic Jacobian is
+    // 100 * (n + 1) residual evaluations); max_lm_iters > 0 additionally caps the LM iterations
+    const long long maxfev = 100ll * ((long long)d.np + 1);
+    const int max_lm = o.max_lm_iters > 0 ? o.max_lm_iters : 0x7fffffff;
     // cg_tol <= 0: automatic.  The LM loop re-evaluates the gradient at every step, so the linear solves need no more
     // accuracy than the step's model deserves: sqrt of the tighter LM tolerance, at most 1e-4 (C3: the same LM steps
     // and the same energies to 1e-12 as with 1e-6, in less than half the CG iterations).
@@ -2544,7 +2548,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
         if (use_graph && !ctx->side_ev && hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming) != hipSuccess) use_graph = false;
         if (!use_graph) (void)hipGetLastError();
     }
-    for (int it = 0; it < o.max_lm_iters && !info; ++it) {
+    for (int it = 0; it < max_lm && !info && stt.nfev < maxfev; ++it) {
         stt.lm_iters = it + 1;
         if (!(f2 == f2) || std::isinf(f2)) {
             set_error("nicp_solve: residual is not finite");
@@ -2562,7 +2566,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
         const double cg_tol_now = o.cg_tol;
         bool accepted = false;
         bool relinearise = false;
-        while (!accepted && !info) {
+        while (!accepted && !info && stt.nfev < maxfev) {
             if (relinearise)  // a rejected trial left the linearisation state at x_trial
                 if (int rc = linearise(ctx, g, w, x, v)) return rc;
             hipLaunchKernelGGL(scaling_kernel, dim3(nbp), dim3(NB), 0, st, w.col2, w.d2, w.lamd2, lam, first_scaling ? 1 : 0, d.np);

@@ -239,14 +239,16 @@ typedef struct nicp_solve_opts {
     double lambda0;          /* initial Levenberg-Marquardt damping (1e-3) */
     double cg_tol;           /* relative residual of the inner conjugate-gradient solve; <= 0 (default): automatic,
                                 min(1e-4, sqrt(min(ftol, xtol))) */
-    int max_lm_iters;        /* outer iterations (100) */
+    int max_lm_iters;        /* cap on the LM iterations; <= 0 (default): none beyond leastsq's own limit of
+                                100 * (n + 1) residual evaluations (MINPACK's maxfev default, nicp_3d.py:351), which
+                                always applies; stats.info = 5 says that a limit ended the solve */
     int max_cg_iters;        /* per linear solve (0 = automatic) */
 } nicp_solve_opts;
 typedef struct nicp_solve_stats {
     double err;  /* sum of squared residuals at the returned P (nicp_3d.py:353) */
     double err0; /* ... at the initial P */
     int lm_iters, cg_iters, nfev;
-    int info;    /* 1 ftol, 2 xtol, 3 both, 4 gtol, 5 iteration limit */
+    int info;    /* 1 ftol, 2 xtol, 3 both, 4 gtol, 5 iteration / evaluation limit */
     int graph_launches; /* 50-iteration CG chunks replayed as one hipGraph (0: plain launches; see ICP_NICP_GRAPH) */
 } nicp_solve_stats;
 
