@@ -9,13 +9,22 @@ tgt = N(0,1)^3 with seed 1, src = ((tgt - shift) Rz(0.3)^T)[perm].  One "step" i
 full ICP iteration: Match (closest point for every source point) + FindTransform
 (Kabsch) + apply + Distance, inputs resident in HBM.  N>1 shards the SOURCE rows over
 the ranks (target replicated), all-reduces 17 doubles per iteration over RCCL (one
-collective) and reports strong scaling (total work fixed).
+collective, issued from inside icp_rigid_run_dist) and reports strong scaling (total work
+fixed).  On every N the timed region is ONE library call that runs K iterations and
+includes the one-time set-up (target grid build + Morton sort of the source shard).
 
 Prints ONE JSON line (rank 0).  `value` = closest-point queries/s over whole ICP
-iterations (= N_src * K / time); `icp_iters_per_s` is the same run in iterations.
+iterations (= N_src * K / time) of the first timed call; `extra.repeats` holds further
+identical calls (median / min / max), `extra.setup_ms` the one-time part of a call.
+`config.check` ties the timed run to the full scan: the correspondences the timed call
+returned are compared with an ICP_FORCE_BRUTE Match of the same final source positions.
 `roofline` is for the dominant kernel (the exact grid closest-point search; --brute: the
-full-scan kernel, bound by fp64 VALU) -- see DESIGN.md section 3.  `cpu_baseline` times the C oracle (test infrastructure, used
-here only as the thing compared against) on the host cores.
+full-scan kernel, bound by fp64 VALU; its roofline is always given as
+roofline.bruteforce_kernel) -- see DESIGN.md section 3.  `extra.nicp_c3` runs config C3
+(10k-vertex NICP with the stiffness schedule) in the reference's mode and in the
+self-consistent one.  `cpu_baseline` times the C oracle (test infrastructure, used here
+only as the thing compared against) on the host cores, and the literal numpy restatement
+of the reference's per-point Closest.
 """
 import argparse
 import json
@@ -41,20 +50,78 @@ def make_cloud(n, seed=1, angle=0.3, shift=(0.1, 0.05, -0.02)):
     return np.ascontiguousarray(src), np.ascontiguousarray(tgt)
 
 
-def cpu_baseline(src, tgt, sample):
-    """C oracle (OpenMP) on a bounded sample of the same workload."""
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(src, tgt, sample, numpy_queries):
+    """C oracle (OpenMP) on a bounded sample of the same workload + the literal numpy restatement of the
+    reference's Closest (icp_3d.py:39-53: one Python iteration per source point) on a few queries and on C1."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
-    threads = min(os.cpu_count() or 1, 16)
+    import icp_oracle as orc
+    nproc = os.cpu_count() or 1
+    threads = min(nproc, 16)
     q = src[:sample]
     c_oracle.match_idx(q[:256], tgt, threads=threads)        # warm up / page in
     t0 = time.perf_counter()
     c_oracle.match_idx(q, tgt, threads=threads)
     dt = time.perf_counter() - t0
-    return {"value": sample / dt, "unit": "queries/s", "cores": threads, "kind": "port",
-            "sample": "%d of the %d source points matched against the full %d-point target by the C oracle "
-                      "(gcc -O3 -ffp-contract=off -fopenmp, %d threads); %.1f s" % (sample, src.shape[0], tgt.shape[0], threads, dt),
-            "pair_evals_per_s": sample * tgt.shape[0] / dt}
+    out = {"value": sample / dt, "unit": "queries/s", "cores": threads, "kind": "port",
+           "sample": "%d of the %d source points matched against the full %d-point target by the C oracle "
+                     "(gcc -O3 -ffp-contract=off -fopenmp, %d threads); %.1f s" % (sample, src.shape[0], tgt.shape[0], threads, dt),
+           "pair_evals_per_s": sample * tgt.shape[0] / dt, "nproc": nproc, "cpu_model": cpu_model()}
+    if numpy_queries > 0:
+        # (i) of SURVEY.md 8d: the numpy restatement, single-threaded by nature
+        t0 = time.perf_counter()
+        for i in range(numpy_queries):
+            orc.closest(tgt, src[i])
+        dq = (time.perf_counter() - t0) / numpy_queries
+        s1, t1 = orc.make_rigid_cloud(1000, seed=0)
+        t0 = time.perf_counter()
+        orc.icp(s1, t1, -np.inf, 30)
+        d1 = time.perf_counter() - t0
+        out["numpy_reference"] = {
+            "kind": "port", "cores": 1, "nproc": nproc, "cpu_model": cpu_model(),
+            "closest_queries_per_s": 1.0 / dq,
+            "closest_sample": "%d queries of the numpy Closest (icp_3d.py:39-42 restated: dset - pt, (disp*disp).sum(1), argmin) "
+                              "against the full %d-point target, %.1f ms per query; a whole Match would take %.1f h (extrapolated)"
+                              % (numpy_queries, tgt.shape[0], dq * 1e3, dq * src.shape[0] / 3600.0),
+            "c1_icp_iters_per_s": 30.0 / d1,
+            "c1_sample": "config C1 in full: ICP(1000 x 1000 points, 30 forced iterations) with the numpy restatement, %.2f s" % d1}
+    return out
+
+
+def nicp_c3(ctx, compat):
+    """BASELINE config C3: nicp_3d.py's outer loop (Deform -> Match -> leastsq -> stiffness halving) on the 10k-vertex
+    synthetic mesh, tol 0.01, up to 50 outer iterations; MINPACK's own stopping rule (no LM cap)."""
+    import torch
+    from icp_amd import nicp
+    sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+    from nicp_bench import make_grid_mesh
+    v, edges, tgt = make_grid_mesh(100, 100, seed=7)
+    w = nicp.knn_weights(v, ctx)
+    P0 = nicp.initial_params(v.shape[0], 3)
+    hist = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dd, P, c = nicp.nicp(P0, w, v, edges, tgt, 0.01, 50, (0.1, 1000.0, 100.0), compat=compat, history=hist, ctx=ctx)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cg = sum(h[3]["cg_iters"] for h in hist)
+    return {"mode": "reference_compat" if compat else "self-consistent", "vertices": int(v.shape[0]), "edges": int(len(edges)),
+            "seconds": dt, "outer_iters": len(hist), "outer_iters_per_s": len(hist) / dt,
+            "lm_iters": sum(h[3]["lm_iters"] for h in hist), "cg_iters": cg, "cg_iters_per_s": cg / dt,
+            "us_per_cg_iter_wall": dt / max(cg, 1) * 1e6, "err_first": hist[0][0], "err_last": hist[-1][0],
+            "final_c_rigid": c[1],
+            "stopped_by": {name: sum(1 for h in hist if h[3]["info"] == code) for code, name in
+                           ((1, "ftol"), (2, "xtol"), (3, "ftol+xtol"), (4, "gtol"), (5, "limit"))}}
 
 
 def main():
@@ -63,10 +130,13 @@ def main():
     ap.add_argument("--steps", type=int, default=30)   # C2: 30 iterations
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=1 << 20, help="source AND target points (default 2^20)")
+    ap.add_argument("--repeats", type=int, default=5, help="further timed calls of K steps after the first (extra.repeats)")
     ap.add_argument("--cpu-sample", type=int, default=262144, help="queries the CPU baseline matches (about 15-20 s on 16 threads)")
+    ap.add_argument("--numpy-queries", type=int, default=64, help="queries of the numpy Closest restatement (0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-nicp", action="store_true", help="skip extra.nicp_c3 (about 20 s)")
+    ap.add_argument("--no-check", action="store_true", help="skip the brute-force check of the timed run's correspondences")
     ap.add_argument("--brute", action="store_true", help="force the brute-force closest-point kernel")
-    ap.add_argument("--roofline-brute", action="store_true", help="also time one brute-force launch (adds ~1 s)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses GPU 0 and the all-reduce goes over gloo")
     args = ap.parse_args()
@@ -80,7 +150,7 @@ def main():
     if args.share_gpu:
         local_rank = 0
         import faulthandler
-        faulthandler.dump_traceback_later(60, exit=True)   # a rehearsal that hangs says where
+        faulthandler.dump_traceback_later(120, exit=True)   # a rehearsal that hangs says where
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:
@@ -97,81 +167,106 @@ def main():
 
     from icp_amd import rigid, _lib
     from icp_amd._lib import get_context, ptr
-    from icp_amd.dist import Comm, GpuOps, ShardedICP, shard_bounds
+    from icp_amd.dist import RigidComm, rigid_icp_dist, shard_bounds
 
     ctx = get_context(local_rank)
     n = args.n
     src, tgt = make_cloud(n, seed=1)
     lo, hi = shard_bounds(n, world, rank)
-    flags = _lib.ICP_FORCE_BRUTE if args.brute else 0
     K, W = args.steps, args.warmup
+    src_d, tgt_d = ctx.to_dev(src[lo:hi]), ctx.to_dev(tgt)
+    n_loc = src_d.shape[0]
+    comm = RigidComm("cuda:%d" % local_rank) if distributed else None
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if not distributed:
-        src_d, tgt_d = ctx.to_dev(src), ctx.to_dev(tgt)
-        if W > 0:
-            rigid.rigid_icp(src_d, tgt_d, 0.0, W, use_tol=False, force_brute=args.brute, ctx=ctx)
+    def run(steps, want_idx=True):
+        """ONE library call = `steps` whole ICP iterations, device-resident, set-up included."""
+        if distributed:
+            return rigid_icp_dist(src_d, tgt_d, 0.0, steps, use_tol=False, force_brute=args.brute, want_idx=want_idx, comm=comm, ctx=ctx)
+        return rigid.rigid_icp(src_d, tgt_d, 0.0, steps, use_tol=False, force_brute=args.brute, want_idx=want_idx, ctx=ctx)
+
+    def timed(steps):
         barrier()
         t0 = time.perf_counter()
-        res = rigid.rigid_icp(src_d, tgt_d, 0.0, K, use_tol=False, force_brute=args.brute, ctx=ctx)
+        res = run(steps)
         barrier()
         dt = time.perf_counter() - t0
-        assert int(res["iters"].cpu()[0]) == K
-        err_last = float(res["err_hist"].cpu()[K - 1])
-    else:
-        ops = GpuOps(ctx, force_brute=args.brute)
-        st = ShardedICP(ops, Comm(), src[lo:hi], tgt)
-        for _ in range(W):
-            st.step()
-        barrier()
+        if distributed:      # MAX over ranks
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.cpu()[0])
+        return dt, res
+
+    if W > 0:
+        run(W)
+    dt, res = timed(K)                                     # the contract's timed region: exactly K steps
+    assert int(res["iters"].cpu()[0]) == K
+    err_last = float(res["err_hist"].cpu()[K - 1])
+    idx_timed = res["idx"].clone()
+    reps = [timed(K)[0] for _ in range(max(args.repeats, 0))] if not args.brute else []
+    # one-time part of a call (target grid + Morton sort + means): a 1-step call minus one marginal step
+    t1 = min(timed(1)[0] for _ in range(3)) if not args.brute else None
+    all_runs = [dt] + reps
+    best = min(all_runs)
+    marginal = (best - t1) / (K - 1) if (t1 is not None and K > 1) else None
+
+    # ---- tie the timed run to the full scan: Match of the final source positions by the brute-force kernel
+    check = None
+    if not args.no_check and not args.brute and float(n_loc) * n <= 2.0 ** 42:   # the full scan of a C4-size shard would take minutes
+        if K > 1:
+            prev = run(K - 1, want_idx=False)["T"]         # deterministic: the same bits as inside the timed call
+            ss = rigid.apply_transform(src_d, prev[:3, :3].contiguous(), prev[3, :3].contiguous(), ctx=ctx)
+        else:
+            ss = src_d
         t0 = time.perf_counter()
-        for _ in range(K):
-            st.step()
-        err = st.flush_err()          # the last iteration's error (earlier ones ride on the next step's all-reduce)
-        barrier()
-        dt = time.perf_counter() - t0
-        err_last = float(err.cpu()[0])
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.cpu()[0])
-        src_d, tgt_d = st.src, st.tgt
+        idx_brute = rigid.closest_indices(ss, tgt_d, force_brute=True, ctx=ctx)
+        torch.cuda.synchronize()
+        ok = torch.tensor([1.0 if torch.equal(idx_brute, idx_timed) else 0.0], dtype=torch.float64,
+                          device="cpu" if (args.share_gpu or not distributed) else "cuda")
+        if distributed:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        check = {"idx_equal_bruteforce": bool(float(ok.cpu()[0]) == 1.0), "n_checked": n,
+                 "what": "correspondences returned by the timed call (last of its %d iterations) vs an ICP_FORCE_BRUTE Match of "
+                         "src . R_%d + t_%d over all %d targets" % (K, K - 1, K - 1, n),
+                 "brute_match_s": time.perf_counter() - t0}
 
     # ---- dominant kernel, timed live with HIP events on the launch stream ----
     # Default path: the exact grid search (grid_query_kernel; the target grid is built once and the
     # queries are in Morton order, as inside icp_rigid_run).  --brute: the full-scan kernel.
-    n_loc = src_d.shape[0]
     idx = ctx.empty((n_loc,), torch.int32)
 
-    def time_closest(fl, reps):
+    def time_closest(fl, reps_):
         ctx.call("icp_closest", ptr(src_d), n_loc, ptr(tgt_d), n, 3, fl, ptr(idx), ptr(None))
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        for _ in range(reps):
+        for _ in range(reps_):
             ctx.call("icp_closest", ptr(src_d), n_loc, ptr(tgt_d), n, 3, fl, ptr(idx), ptr(None))
         ev1.record()
         torch.cuda.synchronize()
-        return ev0.elapsed_time(ev1) * 1e-3 / reps
+        return ev0.elapsed_time(ev1) * 1e-3 / reps_
 
     pairs = float(n_loc) * n
     compulsory = 24.0 * n_loc + 24.0 * n + 4.0 * n_loc
-    t_brute = time_closest(_lib.ICP_FORCE_BRUTE, 2) if (args.brute or args.roofline_brute) else None
-    # per-launch time of the kernel the timed loop spent its time in
+    t_brute = time_closest(_lib.ICP_FORCE_BRUTE, 2) if pairs <= 2.0 ** 42 else None    # ~0.3 s per launch at 2^20 x 2^20
     if args.brute:
         t_kernel = t_brute
     else:
         t_kernel, t_lane, t_defer = rigid.time_grid_query(src_d, tgt_d, reps=max(3, min(K, 10)), ctx=ctx, parts=True)
+    brute_roof = None
+    if t_brute is not None:
+        ab = 8.0 * pairs / t_brute / 1e12
+        brute_roof = {"bound": "valu", "achieved": ab, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": ab / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "kernel": "closest_tiles<3,4,false>",
+                      "kernel_ms": t_brute * 1e3,
+                      "note": "8 fp64 flop per source-target pair x %.3g pairs per launch; peak = MI355X fp64 VECTOR peak "
+                              "(FMA-rated; the reference arithmetic forbids FMA so <= 39.3, and 9 instructions per 8 flop => "
+                              "ceiling ~35 TFLOP/s); VALU-bound, compulsory HBM bytes %.1f MB" % (pairs, compulsory / 1e6)}
     if args.brute:
-        achieved = 8.0 * pairs / t_kernel / 1e12
-        roof = {"bound": "valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
-                "kernel": "closest_tiles<3,4,false>", "kernel_ms": t_kernel * 1e3,
-                "note": "8 fp64 flop per source-target pair x %.3g pairs per launch; peak = MI355X fp64 VECTOR peak "
-                        "(FMA-rated; the reference arithmetic forbids FMA so <= 39.3, and 9 instructions per 8 flop => "
-                        "ceiling ~35 TFLOP/s); VALU-bound, compulsory HBM bytes %.1f MB" % (pairs, compulsory / 1e6)}
+        roof = brute_roof
     else:
         gbytes = 24.0 * n_loc + 4.0 * n_loc + 32.0 * n + 4.0 * (1 << 21)   # queries + idx out + 32-B target records + cell-start array
         achieved = gbytes / t_kernel / 1e9
@@ -192,13 +287,31 @@ def main():
                 roof["traffic_source"] = tr["source"]
         except Exception:
             pass
-        if t_brute is not None:
-            ab = 8.0 * pairs / t_brute / 1e12
-            roof["bruteforce_kernel"] = {"bound": "valu", "achieved": ab, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                                         "unit": "TFLOP/s", "frac": ab / FP64_VECTOR_PEAK_TFLOPS,
-                                         "kernel": "closest_tiles<3,4,false>", "kernel_ms": t_brute * 1e3}
+        if brute_roof is not None:
+            roof["bruteforce_kernel"] = brute_roof
+
+    extra = {"timed_calls_ms_per_step": [t / K * 1e3 for t in all_runs],
+             "repeats": {"calls": len(all_runs), "median_ms_per_step": float(np.median(all_runs)) / K * 1e3,
+                         "min_ms_per_step": min(all_runs) / K * 1e3, "max_ms_per_step": max(all_runs) / K * 1e3},
+             "setup_ms": None if marginal is None else (t1 - marginal) * 1e3,
+             "ms_per_step_without_setup": None if marginal is None else marginal * 1e3,
+             "setup_note": "every timed call includes the one-time target-grid build, the Morton sort of the source shard and "
+                           "the two means (setup_ms, from 1-step calls); ms_per_step_without_setup is the marginal iteration"}
+    if world == 1 and not args.no_nicp and not args.brute:
+        try:
+            extra["nicp_c3"] = {"compat": nicp_c3(ctx, True), "corrected": nicp_c3(ctx, False),
+                                "note": "config C3, whole outer loop per mode; NICP CG kernels: see DESIGN.md 3.3 and profiles/"}
+        except Exception as e:      # the rigid line must survive an NICP failure
+            extra["nicp_c3"] = {"error": repr(e)}
 
     if rank == 0:
+        cfg = {"workload": "%s: rigid ICP, %d source x %d target fp64 points (N(0,1)^3, seed 1, Rz(0.3)+shift, permuted), "
+                           "source rows sharded over %d GPU(s), target replicated" % (
+                               "C2" if n == (1 << 20) else ("C4-size" if n == (1 << 24) else "custom"), n, n, world),
+               "n_source": n, "n_target": n, "dim": 3,
+               "search": "brute-force scan" if args.brute else "exact multi-resolution grid (bit-identical to the scan)",
+               "timed_region": "one icp_rigid_run%s call of K iterations incl. grid build + Morton sort" % ("_dist" if distributed else ""),
+               "last_err": err_last, "check": check}
         out = {
             "metric": "closest-point queries/s over full ICP iterations (Match+FindTransform+apply+Distance), %s pts" % (
                 "1Mx1M" if n == (1 << 20) else "%dx%d" % (n, n)),
@@ -214,15 +327,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%s: rigid ICP, %d source x %d target fp64 points (N(0,1)^3, seed 1, Rz(0.3)+shift, permuted), "
-                                   "source rows sharded over %d GPU(s), target replicated" % (
-                                       "C2" if n == (1 << 20) else ("C4-size" if n == (1 << 24) else "custom"), n, n, world),
-                       "n_source": n, "n_target": n, "dim": 3, "search": "brute-force scan" if args.brute else "exact multi-resolution grid (bit-identical to the scan)",
-                       "last_err": err_last},
+            "config": cfg,
             "roofline": roof,
+            "extra": extra,
         }
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(src, tgt, min(args.cpu_sample, n))
+            out["cpu_baseline"] = cpu_baseline(src, tgt, min(args.cpu_sample, n), args.numpy_queries)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

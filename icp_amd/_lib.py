@@ -47,6 +47,7 @@ _SIGNATURES = {
     "icp_find_transform_noalloc": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_dp],
     "icp_apply_transform": [c_dp, c_dp, c_i64, c_int, c_dp, c_dp, c_dp],
     "icp_rigid_run": [c_dp, c_dp, c_i64, c_dp, c_i64, c_int, c_dbl, c_int, c_int, c_u32, c_dp, c_dp, c_dp, c_dp],
+    "icp_rigid_run_dist": [c_dp, c_dp, c_i64, c_dp, c_i64, c_int, c_dbl, c_int, c_int, c_u32, c_dp, c_dp, c_dp, c_dp, c_dp],
     "icp_shard_sums": [c_dp, c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_dp, c_dp],
     "icp_kabsch_solve": [c_dp, c_dp, c_int, c_dp, c_dp, c_dp, c_dp],
     "icp_shard_apply_err": [c_dp, c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_dp, c_dp, c_dp],

@@ -52,6 +52,7 @@ struct icp_ctx {
     icp::Scratch work_a, work_b, work_c, work_d;  // general work arrays
     icp::Scratch grid_a, grid_b, grid_c, grid_d, grid_e;  // spatial grid over the target
     icp::Scratch sort_a, sort_b, sort_c, sort_d;          // Morton order of the queries
+    icp::Scratch sort_tmp;                                // temporary storage of the stable code sort (stablesort.hip)
     icp::Scratch defer;                                   // grid search: queries handed to the wave-per-query pass
     void *defer_cleared = nullptr;                        // buffer whose two counters are known to be in step
     int defer_parity = 0;                                 // which of the two counters the next search uses
@@ -67,6 +68,8 @@ struct icp_ctx {
 namespace icp {
 int ensure(icp_ctx *ctx, Scratch &s, size_t bytes);
 int noalloc_init(icp_ctx *ctx);  // kabsch.hip
+int stable_sort_codes(icp_ctx *ctx, const uint32_t *codes_in, uint32_t *codes_out, int32_t *idx_tmp, int32_t *idx_out, int64_t m,
+                      int code_bits);  // stablesort.hip
 
 // spatial grid over a target cloud (grid.hip)
 struct GridParams {
@@ -99,9 +102,11 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
 // sidx instead of original indices (icp_rigid_run keeps them that way between iterations: the gathers of the
 // reduction kernels then walk the Morton-sorted copy almost sequentially)
 constexpr unsigned ICP_INTERNAL_POS = 0x10000u;
+// hint_from (with ICP_HINT_IDX): read the hints from this array instead of idx_out (the sharded loop alternates two
+// correspondence buffers)
 int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
                      unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done,
-                     const GridBuild *grid = nullptr);
+                     const GridBuild *grid = nullptr, const int32_t *hint_from = nullptr);
 bool grid_worthwhile(int64_t n, int64_t m, unsigned flags);
 // exact k nearest (k = 6 or 8) by the key fl(sqrt(d2)), ties to the lower index, through a built grid
 int grid_knn(icp_ctx *ctx, const GridBuild &gb, const double *q, int64_t nq, int k, int32_t *idx_out, double *dist_out);

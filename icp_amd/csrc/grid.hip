@@ -208,16 +208,15 @@ __global__ __launch_bounds__(GB) void scan_add_kernel(uint32_t *__restrict__ out
     if (blockIdx.x == 0 && threadIdx.x == 0) out[len] = total_at_end;
 }
 
-// scatter into Morton order; `fill` is a zeroed per-cell cursor
+// Gather into Morton order: sorted position `pos` holds point sidx[pos], the permutation of the stable code sort
+// (stablesort.hip: cells in code order, ascending index inside a cell -- the same order on every run).
 template <int DIM>
 __global__ __launch_bounds__(GB) void scatter_kernel(const double *__restrict__ tgt, uint32_t *code,
-                                                    int64_t m, const uint32_t *__restrict__ start, uint32_t *__restrict__ fill,
-                                                    double *__restrict__ spts, int32_t *__restrict__ sidx,
+                                                    int64_t m, double *__restrict__ spts, const int32_t *__restrict__ sidx,
                                                     double4 *__restrict__ recs) {
-    const int64_t i = (int64_t)blockIdx.x * GB + threadIdx.x;
-    if (i >= m) return;
-    const uint32_t c = code[i];
-    const uint32_t pos = start[c] + atomicAdd(&fill[c], 1u);
+    const int64_t pos = (int64_t)blockIdx.x * GB + threadIdx.x;
+    if (pos >= m) return;
+    const int64_t i = sidx[pos];
     // one 32-byte record per target: coordinates + the original index in the 4th slot, so a
     // candidate costs two 16-byte loads from a single cache line
     double4 rec;
@@ -228,8 +227,7 @@ __global__ __launch_bounds__(GB) void scatter_kernel(const double *__restrict__ 
     recs[pos] = rec;
 #pragma unroll
     for (int a = 0; a < DIM; ++a) spts[(int64_t)pos * DIM + a] = tgt[i * DIM + a];
-    sidx[pos] = (int32_t)i;
-    code[i] = pos;  // the cell code is spent: the array becomes the inverse permutation (GridBuild::inv)
+    code[i] = (uint32_t)pos;  // the cell code is spent: the array becomes the inverse permutation (GridBuild::inv)
 }
 
 __device__ __forceinline__ bool better2(double da, int32_t ia, double db, int32_t ib) {
@@ -875,7 +873,7 @@ int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBui
     const int64_t ncell = 1ll << (dim * bits);
     const int64_t nsb = (ncell + (int64_t)GB * SCAN_ITEMS - 1) / ((int64_t)GB * SCAN_ITEMS);
     if (int rc = ensure(ctx, sa, (size_t)m * (dim + 4) * sizeof(double) + 64)) return rc;   // sorted points | 32-byte records
-    if (int rc = ensure(ctx, sb, (size_t)m * sizeof(int32_t) * 2)) return rc;     // sorted idx | codes
+    if (int rc = ensure(ctx, sb, (size_t)m * sizeof(int32_t) * 4)) return rc;     // sorted idx | codes | sorted codes | 0..m-1
     if (int rc = ensure(ctx, sc, (size_t)(ncell + 1) * sizeof(uint32_t) * 2)) return rc;  // start | count/fill
     if (int rc = ensure(ctx, sd, (size_t)(nsb + 1) * sizeof(uint32_t))) return rc;
     gb.spts = (double *)sa.ptr;
@@ -892,9 +890,9 @@ int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBui
     hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nsb), dim3(GB), 0, st, (const uint32_t *)count, gb.start, bsum, ncell);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, bsum, (int)nsb);
     hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nsb), dim3(GB), 0, st, gb.start, (const uint32_t *)bsum, ncell, (uint32_t)m);
-    ICP_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(uint32_t), st));
-    if (dim == 3) hipLaunchKernelGGL(scatter_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, (const uint32_t *)gb.start, count, gb.spts, gb.sidx, (double4 *)gb.recs);
-    else hipLaunchKernelGGL(scatter_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, (const uint32_t *)gb.start, count, gb.spts, gb.sidx, (double4 *)gb.recs);
+    if (int rc = stable_sort_codes(ctx, codes, codes + m, (int32_t *)(codes + 2 * m), gb.sidx, m, dim * bits)) return rc;
+    if (dim == 3) hipLaunchKernelGGL(scatter_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, gb.spts, (const int32_t *)gb.sidx, (double4 *)gb.recs);
+    else hipLaunchKernelGGL(scatter_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, gb.spts, (const int32_t *)gb.sidx, (double4 *)gb.recs);
     ICP_HIP_CHECK(hipGetLastError());
     gb.gp = gp;
     gb.inv = codes;

@@ -735,6 +735,174 @@ extern "C" int icp_rigid_run(icp_ctx *ctx, const double *src, int64_t n, const d
     return ICP_OK;
 }
 
+// ---------------------------------------------------------------- source-sharded loop
+// One rank's share of icp_3d.py:102-121 with the source rows split over ranks and the target replicated.  Per
+// iteration ONE all-reduce of 17 doubles: the 16 shifted sums of this iteration and the error of the previous one,
+// whose stop test (icp_3d.py:116) is therefore evaluated one Match late -- that Match goes into the other of two
+// correspondence buffers and is discarded.  Every decision is taken on the device from all-reduced values (identical
+// on every rank), so the host enqueues max_iter iterations and max_iter + 2 collectives without reading anything
+// back, and every rank issues the same collectives whatever the stop test says.
+namespace icp {
+
+// buf[0..dim) = local column sums of the source shard, buf[3] = local row count
+__global__ __launch_bounds__(RB) void dist_pack_means_kernel(const double *__restrict__ partial, int nb, double *__restrict__ buf) {
+    __shared__ double tot[kSumSlots];
+    block_reduce_partials(partial, nb, tot);
+    if (threadIdx.x < 3) buf[threadIdx.x] = tot[threadIdx.x];
+    if (threadIdx.x == 3) buf[3] = tot[15];
+}
+__global__ void dist_means_kernel(const double *__restrict__ buf, int dim, RigidState *st) {
+    if (threadIdx.x < dim) st->cs[threadIdx.x] = buf[threadIdx.x] / buf[3];  // np.mean: sum / N (icp_3d.py:69)
+}
+// buf[0..15] = this rank's sums of iteration `it`, buf[16] = its error of iteration it - 1
+__global__ __launch_bounds__(RB) void dist_pack_kernel(const double *__restrict__ partial, int nb, const RigidState *st,
+                                                       int first, double *__restrict__ buf) {
+    __shared__ double tot[kSumSlots];
+    const int done = st->done;
+    if (!done) block_reduce_partials(partial, nb, tot);
+    if (threadIdx.x < kSumSlots) buf[threadIdx.x] = done ? 0.0 : tot[threadIdx.x];
+    if (threadIdx.x == kSumSlots) buf[kSumSlots] = (done || first) ? 0.0 : st->err;
+}
+// after the all-reduce: end-of-iteration bookkeeping of iteration it - 1 (icp_3d.py:114-117), then the solve of `it`
+template <int DIM>
+__global__ void dist_solve_kernel(const double *__restrict__ buf, RigidState *st, int first, double tol, int use_tol,
+                                  double *__restrict__ err_hist) {
+    if (threadIdx.x || blockIdx.x || st->done) return;
+    if (!first) {
+        const double e = st->err_prev, err = buf[kSumSlots];
+        st->err_prev = err;
+        if (err_hist) err_hist[st->iters] = err;
+        st->iters += 1;
+        if (use_tol && (e - err) < tol) {
+            st->done = 1;
+            return;
+        }
+    }
+    for (int k = 0; k < kSumSlots; ++k) st->sums[k] = buf[k];
+    kabsch_from_sums<DIM>(st->sums, st->cs, st->ct, st->R, st->t);
+}
+// local error of this iteration -> st->err (reduced over ranks by the next iteration's collective)
+__global__ __launch_bounds__(RB) void dist_err_kernel(const double *__restrict__ partial, int nb, RigidState *st) {
+    if (st->done) return;
+    __shared__ double red[RB];
+    const int tid = threadIdx.x;
+    double v = 0.0;
+    for (int b = tid; b < nb; b += RB) v += partial[(int64_t)b * kSumSlots];
+    red[tid] = v;
+    __syncthreads();
+    for (int o = RB / 2; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) st->err = red[0];
+}
+__global__ void dist_last_pack_kernel(const RigidState *st, double *__restrict__ buf) { buf[0] = st->done ? 0.0 : st->err; }
+__global__ void dist_last_step_kernel(const double *__restrict__ buf, RigidState *st, double *__restrict__ err_hist) {
+    if (st->done) return;
+    if (err_hist) err_hist[st->iters] = buf[0];
+    st->err_prev = buf[0];
+    st->iters += 1;
+}
+// correspondences of the last EXECUTED iteration: buffer (iters - 1) & 1
+__global__ void dist_unsort_idx_kernel(const int32_t *__restrict__ b0, const int32_t *__restrict__ b1, const RigidState *st,
+                                       const int32_t *__restrict__ order, const int32_t *__restrict__ sidx, int64_t n,
+                                       int32_t *__restrict__ idx_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int32_t v = (((st->iters - 1) & 1) ? b1 : b0)[i];
+        idx_out[order ? order[i] : i] = sidx ? sidx[v] : v;
+    }
+}
+
+static int comm_allreduce(const icp_comm *cm, int count) {
+    if (!cm || cm->world <= 1) return ICP_OK;
+    if (int rc = cm->allreduce_sum(cm->user, count)) {
+        set_error("icp_rigid_run_dist: the all-reduce callback failed (%d)", rc);
+        return ICP_ERR_COMM;
+    }
+    return ICP_OK;
+}
+
+}  // namespace icp
+
+extern "C" int icp_rigid_run_dist(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim, double tol,
+                                  int max_iter, int use_tol, unsigned flags, double *T_out_dev, double *err_hist_dev,
+                                  int32_t *iters_out_dev, int32_t *idx_out, const icp_comm *comm) {
+    ICP_COMMON_ARGS(ctx, dim);
+    ICP_REQUIRE(src && tgt && T_out_dev && comm, "null pointer");
+    ICP_REQUIRE(n > 0 && m > 0 && m < 0x7fffffff, "need n > 0 (every rank holds rows) and 0 < m < 2^31");
+    ICP_REQUIRE(max_iter > 0, "run = 0 leaves R undefined (icp_3d.py:118-120)");
+    ICP_REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, "bad rank / world");
+    ICP_REQUIRE(comm->world == 1 || (comm->reduce_buf_dev && comm->allreduce_sum), "comm buffer / callback missing");
+    if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
+    if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
+    if (int rc = ensure(ctx, ctx->work_c, (size_t)n * dim * sizeof(double))) return rc;
+    if (int rc = ensure(ctx, ctx->work_d, (size_t)n * sizeof(int32_t) * 2)) return rc;
+    GridBuild grid, qsort;
+    if (grid_worthwhile(n, m, flags))
+        if (int rc = grid_build(ctx, tgt, m, dim, grid)) return rc;
+    if (!grid.usable) flags |= ICP_FORCE_BRUTE;
+    const int32_t *order = nullptr;
+    if (grid.usable && n >= 32768) {
+        if (int rc = grid_build(ctx, src, n, dim, qsort, 1)) return rc;
+        if (qsort.usable) {
+            src = qsort.spts;
+            order = qsort.sidx;
+        }
+    }
+    RigidState *st = (RigidState *)ctx->small.ptr;
+    // a single rank needs no buffer from the caller: the 17 doubles live behind the RigidState block
+    double *buf = comm->world > 1 ? comm->reduce_buf_dev : (double *)ctx->small.ptr + 128;
+    static_assert(sizeof(RigidState) <= 128 * sizeof(double), "RigidState overlaps the local reduce buffer");
+    double *ss = (double *)ctx->work_c.ptr, *part = (double *)ctx->partials.ptr;
+    int32_t *ib[2] = {(int32_t *)ctx->work_d.ptr, (int32_t *)ctx->work_d.ptr + n};
+    hipStream_t s = ctx->stream;
+    hipLaunchKernelGGL(rigid_init_kernel, dim3(1), dim3(1), 0, s, st);
+    // global mean of the ORIGINAL source (Q1) from all-reduced column sums; the target is replicated, its mean is local
+    {
+        const int nb = nblocks_for(n);
+        if (dim == 3) hipLaunchKernelGGL(column_sums_kernel<3>, dim3(nb), dim3(RB), 0, s, src, n, part);
+        else hipLaunchKernelGGL(column_sums_kernel<2>, dim3(nb), dim3(RB), 0, s, src, n, part);
+        hipLaunchKernelGGL(dist_pack_means_kernel, dim3(1), dim3(RB), 0, s, (const double *)part, nb, buf);
+        ICP_HIP_CHECK(hipGetLastError());
+        if (int rc = comm_allreduce(comm, 4)) return rc;
+        hipLaunchKernelGGL(dist_means_kernel, dim3(1), dim3(64), 0, s, (const double *)buf, dim, st);
+    }
+    if (int rc = column_sums(ctx, tgt, m, dim, st->ct, 1)) return rc;
+    ICP_HIP_CHECK(hipMemcpyAsync(ss, src, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToDevice, s));  // icp_3d.py:104
+    const int32_t *done = &st->done;
+    const bool pos = grid.usable && !(flags & ICP_FORCE_BRUTE);
+    const double *tgt_rows = pos ? grid.spts : tgt;
+    flags = (flags & ~(unsigned)ICP_HINT_IDX) | (pos ? ICP_INTERNAL_POS : 0u);
+    for (int it = 0; it < max_iter; ++it) {
+        int32_t *idx = ib[it & 1];
+        if (int rc = closest_dispatch(ctx, ss, n, tgt, m, dim, it > 0 ? (flags | ICP_HINT_IDX) : flags, idx, nullptr, done, &grid,
+                                      it > 0 ? ib[(it - 1) & 1] : nullptr))
+            return rc;
+        int nb = 0;
+        if (int rc = shard_sums(ctx, src, tgt_rows, idx, n, dim, st->cs, st->ct, st->sums, done, &nb)) return rc;
+        hipLaunchKernelGGL(dist_pack_kernel, dim3(1), dim3(RB), 0, s, (const double *)part, nb, (const RigidState *)st, it == 0 ? 1 : 0, buf);
+        ICP_HIP_CHECK(hipGetLastError());
+        if (int rc = comm_allreduce(comm, kSumSlots + 1)) return rc;
+        if (dim == 3) hipLaunchKernelGGL(dist_solve_kernel<3>, dim3(1), dim3(64), 0, s, (const double *)buf, st, it == 0 ? 1 : 0, tol, use_tol, err_hist_dev);
+        else hipLaunchKernelGGL(dist_solve_kernel<2>, dim3(1), dim3(64), 0, s, (const double *)buf, st, it == 0 ? 1 : 0, tol, use_tol, err_hist_dev);
+        if (int rc = apply_err(ctx, 1, src, tgt_rows, idx, n, dim, st->R, st->t, ss, st->sums, done, &nb)) return rc;
+        hipLaunchKernelGGL(dist_err_kernel, dim3(1), dim3(RB), 0, s, (const double *)part, nb, st);
+        ICP_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(dist_last_pack_kernel, dim3(1), dim3(1), 0, s, (const RigidState *)st, buf);
+    ICP_HIP_CHECK(hipGetLastError());
+    if (int rc = comm_allreduce(comm, 1)) return rc;
+    hipLaunchKernelGGL(dist_last_step_kernel, dim3(1), dim3(1), 0, s, (const double *)buf, st, err_hist_dev);
+    if (idx_out)
+        hipLaunchKernelGGL(dist_unsort_idx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int32_t *)ib[0],
+                           (const int32_t *)ib[1], (const RigidState *)st, order,
+                           pos ? (const int32_t *)grid.sidx : (const int32_t *)nullptr, n, idx_out);
+    hipLaunchKernelGGL(rigid_finish_kernel, dim3(1), dim3(1), 0, s, (const RigidState *)st, dim, T_out_dev, iters_out_dev);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
 extern "C" int icp_bench_grid_query(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
                                     int reps, double *ms_out_dev) {
     ICP_COMMON_ARGS(ctx, dim);

@@ -1,0 +1,38 @@
+// Stable sort of (cell code, point index) pairs for the Morton ordering of grid.hip.
+//
+// The counting sort of grid.hip used to fill its cells through atomic cursors, so the order of the points INSIDE a
+// cell changed from run to run: harmless for the search (an exact argmin does not depend on the visiting order) but
+// the Kabsch sums of icp_rigid_run run over the Morton-sorted source, and a different order of the same summands moved
+// the transform in its last bits.  A stable LSD radix sort of the codes, with the point indices 0..m-1 as payload,
+// leaves every cell in ascending index order: the ordering, hence every sum over it, is reproducible.
+// The sort itself is rocPRIM's (a plain library operation, once per point set); only the significant code bits
+// are sorted (3 passes at 2^20 points).
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace icp {
+
+__global__ void iota_kernel(int32_t *__restrict__ a, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (int32_t)i;
+}
+
+// idx_out = the permutation that sorts codes_in stably; codes_out = the sorted codes.  idx_tmp: m ints of scratch.
+int stable_sort_codes(icp_ctx *ctx, const uint32_t *codes_in, uint32_t *codes_out, int32_t *idx_tmp, int32_t *idx_out,
+                      int64_t m, int code_bits) {
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, idx_tmp, m);
+    ICP_HIP_CHECK(hipGetLastError());
+    size_t bytes = 0;
+    ICP_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, codes_in, codes_out, (const int32_t *)idx_tmp, idx_out, (size_t)m, 0u,
+                                            (unsigned)code_bits, st));
+    if (int rc = ensure(ctx, ctx->sort_tmp, bytes + 256)) return rc;
+    ICP_HIP_CHECK(rocprim::radix_sort_pairs(ctx->sort_tmp.ptr, bytes, codes_in, codes_out, (const int32_t *)idx_tmp, idx_out, (size_t)m,
+                                            0u, (unsigned)code_bits, st));
+    return ICP_OK;
+}
+
+}  // namespace icp

@@ -12,6 +12,8 @@ The loop is written against a small `ops` interface so the host logic can be
 exercised on CPU (gloo) in tests with a stand-in; the product `GpuOps` calls the
 C-ABI and has no CPU fallback.
 """
+import ctypes
+
 import numpy as np
 
 from . import _lib
@@ -221,3 +223,90 @@ def sharded_icp(ops, comm, src_shard, tgt, tol, run, use_tol=True):
         st.finish_step()
         done += 1
     return st.T(), hist
+
+
+# ---------------------------------------------------------------------------------------------
+# The same loop below Python: icp_rigid_run_dist (include/icp_hip.h) enqueues every iteration itself and calls
+# back only for the all-reduce, so a rank issues no host-language call per kernel and never reads the device
+# inside the loop.  This is what bench.py --gpus N runs; ShardedICP above is the step-by-step form.
+class IcpComm(ctypes.Structure):
+    """icp_comm of include/icp_hip.h"""
+    _fields_ = [("rank", ctypes.c_int), ("world", ctypes.c_int), ("reduce_buf_dev", ctypes.c_void_p),
+                ("user", ctypes.c_void_p), ("allreduce_sum", ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int))]
+
+
+class RigidComm:
+    """The all-reduce callback of icp_comm over torch.distributed.  backend "nccl" (= RCCL): the collective runs on
+    the device buffer, ordered on torch's current stream = the stream the context launches on, no host
+    synchronisation.  Any other backend (gloo: ranks sharing one GPU in rehearsals and tests) stages through the host.
+    `device="cpu"` exercises the protocol without a GPU (tests/test_dist_cpu.py)."""
+
+    def __init__(self, device, group=None, rank=None, world=None):
+        import torch
+        self.torch, self.group = torch, group
+        self.dist = None
+        if world is None or world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            rank = dist.get_rank(group) if rank is None else rank
+            world = dist.get_world_size(group) if world is None else world
+        self.rank, self.world = int(rank or 0), int(world)
+        self.reduce_buf = torch.zeros(32, dtype=torch.float64, device=device)
+        self.native = self.world > 1 and self.reduce_buf.is_cuda and self.dist.get_backend(group) == "nccl"
+        self.calls = []          # doubles per collective, in call order
+        self.error = None
+        self._cb = IcpComm._fields_[4][1](self._allreduce)
+        self.struct = IcpComm(self.rank, self.world, ctypes.c_void_p(self.reduce_buf.data_ptr()), None, self._cb)
+
+    def allreduce(self, count):
+        self.calls.append(count)
+        if self.world == 1:
+            return
+        buf = self.reduce_buf[:count]
+        if self.native:
+            self.dist.all_reduce(buf, group=self.group)
+        else:
+            h = buf.cpu()
+            self.dist.all_reduce(h, group=self.group)
+            buf.copy_(h)
+
+    def _allreduce(self, user, count):
+        try:
+            self.allreduce(count)
+            return 0
+        except Exception as e:          # never let an exception cross the C frames
+            self.error = e
+            return 1
+
+
+def rigid_icp_dist(src_shard, target, tol, run, use_tol=True, compare_sqrt=False, force_brute=False, want_idx=False,
+                   comm=None, ctx=None):
+    """Source-sharded ICP through icp_rigid_run_dist.  Every rank passes its rows of the source and the whole target;
+    returns dict(T, err_hist, iters[, idx]) of device tensors, T / err_hist / iters identical on all ranks, idx for the
+    rank's own rows."""
+    ctx = ctx or _lib.get_context()
+    torch = ctx.torch
+    src, tgt = ctx.to_dev(src_shard), ctx.to_dev(target)
+    if src.dim() != 2 or src.shape[1] not in (2, 3) or tgt.dim() != 2 or tgt.shape[1] != src.shape[1]:
+        raise ValueError("points must be [N, dim] with dim 2 or 3 on both sides")
+    dim, run = src.shape[1], int(run)
+    if run <= 0:
+        raise NameError("name 'R' is not defined")          # icp_3d.py:118-120
+    comm = comm or RigidComm("cuda:%d" % ctx.device)
+    T = ctx.empty((dim + 1, dim + 1))
+    hist = ctx.empty((run,))
+    iters = ctx.empty((1,), torch.int32)
+    idx = ctx.empty((src.shape[0],), torch.int32) if want_idx else None
+    flags = (_lib.ICP_COMPARE_SQRT if compare_sqrt else 0) | (_lib.ICP_FORCE_BRUTE if force_brute else 0)
+    comm.error = None
+    try:
+        ctx.call("icp_rigid_run_dist", ptr(src), src.shape[0], ptr(tgt), tgt.shape[0], dim, ctypes.c_double(float(tol)), run,
+                 1 if use_tol else 0, flags, ptr(T), ptr(hist), ptr(iters), ptr(idx), ctypes.byref(comm.struct))
+    except _lib.IcpHipError:
+        if comm.error is not None:
+            raise comm.error
+        raise
+    out = dict(T=T, err_hist=hist, iters=iters)
+    if want_idx:
+        out["idx"] = idx
+    return out

@@ -161,6 +161,26 @@ int icp_shard_apply_err(icp_ctx *ctx, const double *src, const double *tgt, cons
 /* column sums of a [n,dim] array -> out_dev[dim] (for the shifts above) */
 int icp_column_sums(icp_ctx *ctx, const double *a, int64_t n, int dim, double *out_dev);
 
+/* The same loop as icp_rigid_run with the SOURCE ROWS sharded over ranks (one process per GPU) and the target
+ * replicated: icp_3d.py:102-121 needs one exchange per iteration, the sums behind
+ * FindTransform.  The library never talks to the network itself: it calls `allreduce_sum`, which the host implements
+ * over RCCL / MPI / torch.distributed; the callback must be ordered after the work already queued on the context's
+ * stream and must have completed, or be ordered on that stream, when it returns (0 = success).  Per call every rank
+ * issues exactly max_iter + 2 collectives (4 doubles once, 17 per iteration, 1 at the end) whatever the stop test
+ * decides -- decisions are taken on the device from all-reduced values, so the host never reads anything back inside
+ * the loop.  src is the rank's shard [n_local, dim]; T / err_hist / iters are identical on all ranks; idx_out
+ * [n_local] are the shard's correspondences of the last executed iteration.  world = 1 runs without callbacks and
+ * returns what icp_rigid_run returns, bit for bit.  No counterpart in the reference (single process). */
+typedef struct icp_comm {
+    int rank, world;
+    double *reduce_buf_dev; /* >= 32 doubles (device); allreduce_sum sums its first `count` entries over ranks in place */
+    void *user;
+    int (*allreduce_sum)(void *user, int count);
+} icp_comm;
+int icp_rigid_run_dist(icp_ctx *ctx, const double *src_local, int64_t n_local, const double *tgt, int64_t m, int dim,
+                       double tol, int max_iter, int use_tol, unsigned flags, double *T_out_dev, double *err_hist_dev,
+                       int32_t *iters_out_dev, int32_t *idx_out, const icp_comm *comm);
+
 /* Measurement hook (no counterpart in the reference): builds the target grid and the Morton
  * order of the queries exactly as icp_rigid_run does, then times `reps` grid searches with HIP
  * events on the context's stream.  ms_out_dev[3] = average milliseconds of {one whole search,

@@ -250,7 +250,8 @@ def test_bench_contract_line():
     import json
     import sys
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                          "--n", "65536", "--cpu-sample", "2048"], capture_output=True, text=True, timeout=300)
+                          "--n", "65536", "--cpu-sample", "2048", "--numpy-queries", "2", "--no-nicp", "--repeats", "2"],
+                         capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -265,3 +266,9 @@ def test_bench_contract_line():
     assert r["bound"] in ("hbm", "mfma", "valu") and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["nproc"] >= 1 and c["cpu_model"] and c["numpy_reference"]["closest_queries_per_s"] > 0
+    assert d["config"]["check"] == dict(d["config"]["check"], idx_equal_bruteforce=True, n_checked=65536)
+    assert r["bruteforce_kernel"]["bound"] == "valu" and r["bruteforce_kernel"]["frac"] > 0
+    e = d["extra"]
+    assert len(e["timed_calls_ms_per_step"]) == 3 and e["repeats"]["min_ms_per_step"] <= d["ms_per_step"] <= e["repeats"]["max_ms_per_step"]
+    assert e["setup_ms"] is not None

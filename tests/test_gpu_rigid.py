@@ -1,5 +1,7 @@
 """GPU parity tests for the rigid-ICP path: HIP (through the C-ABI) vs the oracle.
 Indices must be bit-exact; transforms within 1e-6 relative (north_star)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -151,9 +153,8 @@ def test_float32_and_other_dtype_tensors_are_converted(api):
 def test_calls_under_two_streams_are_ordered(api):
     """the context's scratch assumes one stream.  icp_rigid_run issued under stream A and,
     without any host synchronisation, icp_closest under stream B share scratch buffers: the context orders B after
-    A (event wait in icp_ctx_set_stream), so both return what they return when run alone (correspondences and
-    squared distances bit for bit; the transform to 1e-13: the Morton sort of the source fills its cells through
-    atomic counters, so the order of the sums -- not their value beyond the last bits -- varies run to run)."""
+    A (event wait in icp_ctx_set_stream), so both return what they return when run alone -- bit for bit, the
+    transform included (the Morton ordering of the source is a stable sort, so every sum has a fixed order)."""
     torch = api["torch"]
     rigid = api["rigid"]
     src, tgt = orc.make_rigid_cloud(200000, seed=9)
@@ -177,8 +178,7 @@ def test_calls_under_two_streams_are_ordered(api):
             r2 = rigid.rigid_icp(sd, td, -np.inf, 6, want_idx=True)
         torch.cuda.synchronize()
         for out in (r, r2):
-            assert torch.equal(out["idx"], alone_idx)
-            np.testing.assert_allclose(out["T"].cpu().numpy(), alone_T.cpu().numpy(), rtol=1e-13, atol=1e-13)
+            assert torch.equal(out["idx"], alone_idx) and torch.equal(out["T"], alone_T)
         assert torch.equal(c[0], alone_c[0]) and torch.equal(c[1], alone_c[1])
 
 
@@ -312,3 +312,79 @@ def test_match_c4_size_properties(api):
     pick = rng.choice(n, 256, replace=False)
     oi, _ = c_oracle.match_idx(src[pick], tgt)
     assert np.array_equal(idx[pick], oi)
+
+
+# ---------------------------------------------------------------- icp_rigid_run_dist (source-sharded loop below Python)
+@pytest.mark.parametrize("n,m,tol,run,dim", [(60000, 50000, 0.10, 50, 3), (40000, 45000, -np.inf, 7, 3), (3000, 2500, 0.05, 30, 2),
+                                             (500, 700, 0.10, 50, 3)])
+def test_rigid_run_dist_world1_equals_rigid_run(api, n, m, tol, run, dim):
+    """One rank, no callbacks: the piggy-backed loop (stop test one Match late, two correspondence buffers) returns
+    what icp_rigid_run returns, bit for bit -- transform, error history, iteration count, last correspondences."""
+    from icp_amd import dist as icpdist
+    rng = np.random.default_rng(n + m)
+    tgt = rng.standard_normal((m, dim))
+    A = orc.rot_matrix(0.05, -0.04, 0.06) if dim == 3 else orc.rot2(0.05)
+    src = (tgt[rng.permutation(m)[:n] % m] - 0.02) @ A.T if n <= m else rng.standard_normal((n, dim))
+    a = api["rigid"].rigid_icp(src, tgt, tol, run, want_idx=True)
+    cm = icpdist.RigidComm("cuda", rank=0, world=1)
+    b = icpdist.rigid_icp_dist(src, tgt, tol, run, want_idx=True, comm=cm)
+    api["torch"].cuda.synchronize()
+    k = int(a["iters"].cpu()[0])
+    assert k == int(b["iters"].cpu()[0]) and 1 <= k <= run
+    assert api["torch"].equal(a["T"], b["T"])
+    assert api["torch"].equal(a["err_hist"][:k], b["err_hist"][:k])
+    assert api["torch"].equal(a["idx"], b["idx"])
+    assert cm.calls == []                                   # a single rank never calls back
+
+
+def _dist_worker(rank, world, port, q, n, m, tol, run, seed):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from icp_amd import dist as icpdist
+        src, tgt = orc.make_rigid_cloud(m, seed=seed)
+        src = src[:n]
+        lo, hi = icpdist.shard_bounds(n, world, rank)
+        cm = icpdist.RigidComm("cuda:0")
+        out = icpdist.rigid_icp_dist(src[lo:hi], tgt, tol, run, want_idx=True, comm=cm)
+        torch.cuda.synchronize()
+        q.put((rank, dict(T=out["T"].cpu().numpy(), hist=out["err_hist"].cpu().numpy(), iters=int(out["iters"].cpu()[0]),
+                          idx=out["idx"].cpu().numpy(), calls=list(cm.calls))))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,m,tol,run", [(90000, 100000, 0.10, 50), (70001, 80000, -np.inf, 6)])
+def test_rigid_run_dist_two_ranks_one_gpu(api, n, m, tol, run):
+    """Two ranks (sharing the test box's one GPU, all-reduce over gloo with host staging): same correspondences as
+    the single-GPU loop bit for bit, transform / errors to 1e-12 (the sums are added in another order), identical on
+    both ranks, and exactly run + 2 collectives per rank of 4, 17 ... 17, 1 doubles whatever the stop test says."""
+    import torch.multiprocessing as mp
+    src, tgt = orc.make_rigid_cloud(m, seed=13)
+    src = src[:n]
+    ref = api["rigid"].rigid_icp(src, tgt, tol, run, want_idx=True)
+    api["torch"].cuda.synchronize()
+    k = int(ref["iters"].cpu()[0])
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [mpc.Process(target=_dist_worker, args=(r, 2, port, q, n, m, tol, run, 13)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [o for _, o in sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for o in res:
+        assert o["iters"] == k
+        np.testing.assert_allclose(o["T"], ref["T"].cpu().numpy(), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(o["hist"][:k], ref["err_hist"].cpu().numpy()[:k], rtol=1e-12)
+        assert o["calls"] == [4] + [17] * run + [1]
+    assert np.array_equal(res[0]["T"], res[1]["T"]) and np.array_equal(res[0]["hist"][:k], res[1]["hist"][:k])
+    assert np.array_equal(np.concatenate([res[0]["idx"], res[1]["idx"]]), ref["idx"].cpu().numpy())
