@@ -137,6 +137,9 @@ def main():
     ap.add_argument("--no-nicp", action="store_true", help="skip extra.nicp_c3 (about 20 s)")
     ap.add_argument("--no-check", action="store_true", help="skip the brute-force check of the timed run's correspondences")
     ap.add_argument("--brute", action="store_true", help="force the brute-force closest-point kernel")
+    ap.add_argument("--rehearse-comm", action="store_true",
+                    help="one process, one GPU: run the SHARDED entry point with a one-rank RCCL group and make the library "
+                         "call back every collective (measures the host cost of the multi-GPU path on one GPU)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses GPU 0 and the all-reduce goes over gloo")
     args = ap.parse_args()
@@ -177,6 +180,15 @@ def main():
     src_d, tgt_d = ctx.to_dev(src[lo:hi]), ctx.to_dev(tgt)
     n_loc = src_d.shape[0]
     comm = RigidComm("cuda:%d" % local_rank) if distributed else None
+    if args.rehearse_comm and not distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        dist.all_reduce(torch.zeros(17, dtype=torch.float64, device="cuda"))
+        comm = RigidComm("cuda:%d" % local_rank)
+        comm.world, comm.native = 2, True        # Python side: really all-reduce (over the one-rank RCCL group)
+        comm.struct.world = 2                    # library side: call back for every collective
 
     def barrier():
         if distributed:
@@ -185,7 +197,7 @@ def main():
 
     def run(steps, want_idx=True):
         """ONE library call = `steps` whole ICP iterations, device-resident, set-up included."""
-        if distributed:
+        if distributed or comm is not None:
             return rigid_icp_dist(src_d, tgt_d, 0.0, steps, use_tol=False, force_brute=args.brute, want_idx=want_idx, comm=comm, ctx=ctx)
         return rigid.rigid_icp(src_d, tgt_d, 0.0, steps, use_tol=False, force_brute=args.brute, want_idx=want_idx, ctx=ctx)
 
@@ -310,7 +322,9 @@ def main():
                                "C2" if n == (1 << 20) else ("C4-size" if n == (1 << 24) else "custom"), n, n, world),
                "n_source": n, "n_target": n, "dim": 3,
                "search": "brute-force scan" if args.brute else "exact multi-resolution grid (bit-identical to the scan)",
-               "timed_region": "one icp_rigid_run%s call of K iterations incl. grid build + Morton sort" % ("_dist" if distributed else ""),
+               "timed_region": "one icp_rigid_run%s call of K iterations incl. grid build + Morton sort" % (
+                   "_dist" if (distributed or comm is not None) else "") + (
+                   " (REHEARSAL: one rank, every collective really issued on a one-rank RCCL group)" if args.rehearse_comm else ""),
                "last_err": err_last, "check": check}
         out = {
             "metric": "closest-point queries/s over full ICP iterations (Match+FindTransform+apply+Distance), %s pts" % (
@@ -338,6 +352,7 @@ def main():
         print(json.dumps(out))
     if distributed:
         dist.barrier()
+    if distributed or args.rehearse_comm:
         dist.destroy_process_group()
 
 
