@@ -764,6 +764,332 @@ __global__ __launch_bounds__(NB) void jtu_kernel(const double *__restrict__ P, c
     }
 }
 
+// ------------------------------------------------------------------ fused CG operator: out = J^T W^2 J p + lam_d2 .* p
+// The CG operator never needs y = J p as a vector: jp_kernel wrote its 9N + 6E entries (27 doubles per vertex at
+// E = 3N) and jtu_kernel read them back through gathers, about half of the memory-side traffic of the pair
+// (profiles/r2_pmc_nicp200k_before.txt).  Only the FIT rows couple a vertex to the parameters of other vertices'
+// neighbours (two hops), so only they keep an intermediate: fitrow_kernel writes dim doubles per vertex, and
+// normal_kernel forms the rigidity rows (local) and the smoothness rows (from the two endpoint blocks of p) in
+// registers.  Every row value and every sum is formed by the same operations in the same order as in
+// jp_kernel(sq = 1) -> jtu_kernel, so the result is bit-identical to that pair (ICP_NICP_FUSEDOP=0 runs the pair;
+// test_fused_operator_is_bit_identical).
+template <int DIM, bool COMPAT>
+__global__ __launch_bounds__(NB) void fitrow_kernel(const double *__restrict__ p, const int32_t *__restrict__ nbr,
+                                                   const double *__restrict__ wt, int K, const double *__restrict__ v,
+                                                   const double *__restrict__ rs, int64_t n, const Globals *__restrict__ g,
+                                                   double c_fit, double *__restrict__ yfit, Strides st, RowW rw) {
+    constexpr int S = Lay<DIM>::S, NANG = Lay<DIM>::NANG;
+    const int64_t t = (int64_t)vblock() * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const double *ptail = p + n * S;
+    if (rw.f2) c_fit *= rw.f2[t];
+    double vi[DIM], acc[DIM];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+        vi[c] = v[t * st.vj + c * st.vc];
+        acc[c] = 0.0;
+    }
+    for (int k0 = 0; k0 < K; k0 += 4) {  // four neighbours per batch: all gathers issued before use
+        int32_t jj[4];
+        double ww[4], pj[4][S], vn[4][DIM];
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4) {
+            const int kk = k0 + b4 < K ? k0 + b4 : K - 1;
+            jj[b4] = nbr[t * K + kk];
+            ww[b4] = k0 + b4 < K ? wt[t * K + kk] : 0.0;
+        }
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4) {
+#pragma unroll
+            for (int e = 0; e < S; ++e) pj[b4][e] = p[(int64_t)jj[b4] * st.pj + e * st.pe];
+#pragma unroll
+            for (int r = 0; r < DIM; ++r) vn[b4][r] = v[(int64_t)jj[b4] * st.vj + r * st.vc];
+        }
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4) {
+            const double w = ww[b4];
+            if (w == 0.0) continue;
+            const double wb = (DIM == 2 && COMPAT) ? 1.0 : w;  // Q7
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                double a = 0.0;
+#pragma unroll
+                for (int r = 0; r < DIM; ++r) a += (vi[r] - vn[b4][r]) * pj[b4][r * DIM + c];
+                acc[c] += w * a + wb * pj[b4][DIM * DIM + c];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < DIM; ++o) {
+        double a = ptail[NANG + o];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) a += acc[c] * g->R[c * DIM + o];
+        for (int an = 0; an < NANG; ++an) {
+            double b = 0.0;
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) b += rs[t * st.vj + c * st.vc] * g->dR[an][c * DIM + o];
+            a += ptail[an] * b;
+        }
+        yfit[t * st.fj + o * st.fo] = -c_fit * a;
+    }
+}
+
+template <int DIM, bool COMPAT>
+__global__ __launch_bounds__(NB) void normal_kernel(const double *__restrict__ P, const double *__restrict__ p,
+                                                   const double *__restrict__ yfit, const double *__restrict__ v,
+                                                   const double *__restrict__ rs, const int32_t *__restrict__ rev_ptr,
+                                                   const int32_t *__restrict__ rev_i, const double *__restrict__ rev_w,
+                                                   const int32_t *__restrict__ inc_ptr, const int32_t *__restrict__ inc_ent,
+                                                   const int32_t *__restrict__ inc_other, int64_t n,
+                                                   const Globals *__restrict__ g, double c_fit, double c_rigid, double c_smooth,
+                                                   const double *__restrict__ lam_d2, double lam, double *__restrict__ out,
+                                                   double *__restrict__ partial, int64_t nown, Strides st, RowW rw) {
+    constexpr int S = Lay<DIM>::S, NANG = Lay<DIM>::NANG, NG = Lay<DIM>::NG, NA = Lay<DIM>::NA;
+    const int64_t j = (int64_t)vblock() * blockDim.x + threadIdx.x;
+    double gacc[kSumSlots];
+#pragma unroll
+    for (int k = 0; k < kSumSlots; ++k) gacc[k] = 0.0;
+    if (j < n) {
+        double gA[DIM][DIM], gb[DIM], vj[DIM], pown[S], Aown[NA], Rm[DIM][DIM];
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) {
+            vj[r] = v[j * st.vj + r * st.vc];
+            gb[r] = 0.0;
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) gA[r][c] = 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c)
+#pragma unroll
+            for (int o = 0; o < DIM; ++o) Rm[c][o] = g->R[c * DIM + o];
+        constexpr int RB = 4, IB = 3;  // fit rows / edges per batch (an edge brings a whole 12-double block of p)
+        const int32_t rv_beg = rev_ptr[j], rv_end = rev_ptr[j + 1], in_beg = inc_ptr[j], in_end = inc_ptr[j + 1];
+        const int32_t rv_cl = rv_end > rv_beg ? rv_end - 1 : 0, in_cl = in_end > in_beg ? in_end - 1 : 0;
+
+        auto fit_entries = [&](int32_t e0, int32_t (&ii)[RB], double (&ww)[RB]) {
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const int32_t ee = e0 + q < rv_end ? e0 + q : rv_cl;
+                ii[q] = rev_i[ee];
+                ww[q] = e0 + q < rv_end ? rev_w[ee] : 0.0;
+            }
+        };
+        auto fit_gather = [&](const int32_t (&ii)[RB], double (&uu)[RB][DIM], double (&vv)[RB][DIM]) {
+#pragma unroll
+            for (int q = 0; q < RB; ++q)
+#pragma unroll
+                for (int o = 0; o < DIM; ++o) {
+                    uu[q][o] = yfit[(int64_t)ii[q] * st.fj + o * st.fo];
+                    vv[q][o] = v[(int64_t)ii[q] * st.vj + o * st.vc];
+                }
+        };
+        auto fit_accumulate = [&](const double (&ww)[RB], const double (&uu)[RB][DIM], const double (&vv)[RB][DIM]) {
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const double w = ww[q];
+                if (w == 0.0) continue;
+                const double wb = (DIM == 2 && COMPAT) ? 1.0 : w;
+                double yv[DIM];
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int o = 0; o < DIM; ++o) a += Rm[c][o] * uu[q][o];
+                    yv[c] = a;
+                }
+#pragma unroll
+                for (int r = 0; r < DIM; ++r) {
+                    const double d = vv[q][r] - vj[r];
+#pragma unroll
+                    for (int c = 0; c < DIM; ++c) gA[r][c] += -c_fit * w * d * yv[c];
+                }
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) gb[c] += -c_fit * wb * yv[c];
+            }
+        };
+        auto edge_entries = [&](int32_t e0, int32_t (&ent)[IB], int32_t (&oth)[IB]) {
+#pragma unroll
+            for (int q = 0; q < IB; ++q) {
+                const int32_t ee = e0 + q < in_end ? e0 + q : in_cl;
+                ent[q] = inc_ent[ee];
+                oth[q] = inc_other[ee];
+            }
+        };
+        auto edge_gather = [&](const int32_t (&ent)[IB], const int32_t (&oth)[IB], double (&po)[IB][S], double (&vo)[IB][DIM],
+                               double (&e2)[IB]) {
+#pragma unroll
+            for (int q = 0; q < IB; ++q) {
+#pragma unroll
+                for (int o = 0; o < DIM; ++o) vo[q][o] = v[(int64_t)oth[q] * st.vj + o * st.vc];
+#pragma unroll
+                for (int e = 0; e < S; ++e) po[q][e] = p[(int64_t)oth[q] * st.pj + e * st.pe];
+                const double ew = rw.edge ? rw.edge[ent[q] >> 1] : 1.0;
+                e2[q] = rw.edge ? ew * ew : 1.0;
+            }
+        };
+        // smoothness rows of one incident edge (nicp_3d.py:316-333), as jp_kernel forms them with sq = 1, and their
+        // J^T contributions to THIS endpoint, as jtu_kernel adds them
+        auto edge_accumulate = [&](int32_t e0, const int32_t (&ent)[IB], const double (&po)[IB][S], const double (&vo)[IB][DIM],
+                                   const double (&e2)[IB]) {
+#pragma unroll
+            for (int q = 0; q < IB; ++q) {
+                if (e0 + q >= in_end) continue;
+                const int end = ent[q] & 1;
+                const double cs2 = rw.edge ? c_smooth * e2[q] : c_smooth;
+                double d[DIM];
+#pragma unroll
+                for (int r = 0; r < DIM; ++r) d[r] = end == 0 ? vo[q][r] - vj[r] : vj[r] - vo[q][r];
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) {
+                    double a1 = 0.0, a2 = 0.0;  // d . (A-part of p of endpoint 1 / endpoint 2)[:, c]
+#pragma unroll
+                    for (int r = 0; r < DIM; ++r) {
+                        const double q1 = end == 0 ? pown[r * DIM + c] : po[q][r * DIM + c];
+                        const double q2 = end == 0 ? po[q][r * DIM + c] : pown[r * DIM + c];
+                        a1 += d[r] * q1;
+                        a2 += d[r] * q2;
+                    }
+                    const double b1 = end == 0 ? pown[DIM * DIM + c] : po[q][DIM * DIM + c];
+                    const double b2 = end == 0 ? po[q][DIM * DIM + c] : pown[DIM * DIM + c];
+                    const double u0 = cs2 * (a1 + b1 - b2), u1 = cs2 * (-a2 + b2 - b1);
+#pragma unroll
+                    for (int r = 0; r < DIM; ++r) gA[r][c] += end == 0 ? c_smooth * d[r] * u0 : -c_smooth * d[r] * u1;
+                    gb[c] += end == 0 ? c_smooth * (u0 - u1) : c_smooth * (u1 - u0);
+                }
+            }
+        };
+
+        // first batches of both lists + the vertex's own blocks: entries, then every gather
+        int32_t ii0[RB], ent0[IB], oth0[IB];
+        double ww0[RB], uu0[RB][DIM], vv0[RB][DIM], po0[IB][S], vo0[IB][DIM], e20[IB];
+        fit_entries(rv_beg, ii0, ww0);
+        edge_entries(in_beg, ent0, oth0);
+#pragma unroll
+        for (int e = 0; e < NA; ++e) Aown[e] = P[j * st.pj + e * st.pe];
+#pragma unroll
+        for (int e = 0; e < S; ++e) pown[e] = p[j * st.pj + e * st.pe];
+        fit_gather(ii0, uu0, vv0);
+        edge_gather(ent0, oth0, po0, vo0, e20);
+
+        fit_accumulate(ww0, uu0, vv0);
+        for (int32_t e0 = rv_beg + RB; e0 < rv_end; e0 += RB) {
+            int32_t ii[RB];
+            double ww[RB], uu[RB][DIM], vv[RB][DIM];
+            fit_entries(e0, ii, ww);
+            fit_gather(ii, uu, vv);
+            fit_accumulate(ww, uu, vv);
+        }
+        // rigidity rows of vertex j: y = W^2 G pa (jp_kernel), then G^T y (jtu_kernel)
+        {
+            double cr = c_rigid;
+            if (rw.rig) cr *= rw.rig[j] * rw.rig[j];
+            const double *A = Aown, *pa = pown;
+            if constexpr (DIM == 3) {
+                double d01 = 0, d10 = 0, d12 = 0, d21 = 0, d20 = 0, d02 = 0, d00 = 0, d11 = 0, d22 = 0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    d10 += A[3 + c] * pa[c];
+                    d01 += A[c] * pa[3 + c];
+                    d21 += A[6 + c] * pa[3 + c];
+                    d12 += A[3 + c] * pa[6 + c];
+                    d20 += A[6 + c] * pa[c];
+                    d02 += A[c] * pa[6 + c];
+                    d00 += A[c] * pa[c];
+                    d11 += A[3 + c] * pa[3 + c];
+                    d22 += A[6 + c] * pa[6 + c];
+                }
+                const double ur[6] = {cr * (d10 + d01), cr * (d21 + d12), cr * (d20 + d02), cr * (-2 * d00), cr * (-2 * d11), cr * (-2 * d22)};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double a0 = A[c], a1 = A[3 + c], a2 = A[6 + c];
+                    gA[0][c] += c_rigid * (ur[0] * a1 + ur[2] * a2 - 2 * ur[3] * a0);
+                    gA[1][c] += c_rigid * (ur[0] * a0 + ur[1] * a2 - 2 * ur[4] * a1);
+                    gA[2][c] += c_rigid * (ur[1] * a1 + ur[2] * a0 - 2 * ur[5] * a2);
+                }
+            } else {
+                double d10 = 0, d01 = 0, d00 = 0, d11 = 0;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    d10 += A[2 + c] * pa[c];
+                    d01 += A[c] * pa[2 + c];
+                    d00 += A[c] * pa[c];
+                    d11 += A[2 + c] * pa[2 + c];
+                }
+                const double ur[3] = {cr * (d10 + d01), cr * (-2 * d00), cr * (-2 * d11)};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const double a0 = A[c], a1 = A[2 + c];
+                    gA[0][c] += c_rigid * (ur[0] * a1 - 2 * ur[1] * a0);
+                    gA[1][c] += c_rigid * (ur[0] * a0 - 2 * ur[2] * a1);
+                }
+            }
+        }
+        // smoothness rows of the edges incident to vertex j
+        edge_accumulate(in_beg, ent0, po0, vo0, e20);
+        for (int32_t e0 = in_beg + IB; e0 < in_end; e0 += IB) {
+            int32_t ent[IB], oth[IB];
+            double po[IB][S], vo[IB][DIM], e2[IB];
+            edge_entries(e0, ent, oth);
+            edge_gather(ent, oth, po, vo, e2);
+            edge_accumulate(e0, ent, po, vo, e2);
+        }
+        double pap = 0.0;
+#pragma unroll
+        for (int r = 0; r < DIM; ++r)
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                const int64_t o = j * st.pj + (r * DIM + c) * st.pe;
+                const double val = gA[r][c] + lam * lam_d2[o] * pown[r * DIM + c];
+                out[o] = val;
+                pap += val * pown[r * DIM + c];
+            }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            const int64_t o = j * st.pj + (DIM * DIM + c) * st.pe;
+            const double val = gb[c] + lam * lam_d2[o] * pown[DIM * DIM + c];
+            out[o] = val;
+            pap += val * pown[DIM * DIM + c];
+        }
+        gacc[8] = pap;  // vertex part of p . (A p), summed by the tail kernels
+        // global columns: vertex j as fit row j
+        double uown[DIM];
+#pragma unroll
+        for (int o = 0; o < DIM; ++o) uown[o] = yfit[j * st.fj + o * st.fo];
+        for (int an = 0; an < NANG; ++an) {
+            double a = 0.0;
+#pragma unroll
+            for (int o = 0; o < DIM; ++o) {
+                double b = 0.0;
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) b += rs[j * st.vj + c * st.vc] * g->dR[an][c * DIM + o];
+                a += -c_fit * b * uown[o];
+            }
+            gacc[an] = a;
+        }
+#pragma unroll
+        for (int o = 0; o < DIM; ++o) gacc[NANG + o] = -c_fit * uown[o];
+    }
+    // halo copies (j >= nown) belong to another rank's sums
+    if (j >= nown) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gacc[k] = 0.0;
+    }
+    __shared__ double red[NB / 64][9];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (k >= NG && k != 8) continue;
+        const double sv = wave_sum(gacc[k]);
+        if ((tid & 63) == 0) red[tid >> 6][k] = sv;
+    }
+    __syncthreads();
+    if (tid < 9 && (tid < NG || tid == 8)) {
+        double sv = red[0][tid];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) sv += red[w][tid];
+        partial[(j / blockDim.x) * kSumSlots + tid] = sv;
+    }
+}
+
 // ------------------------------------------------------------------ vector kernels
 // device scalars used by the CG / LM loops
 struct Scal {
@@ -914,7 +1240,10 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
                                                        double c_smooth, const double *__restrict__ col2,
                                                        const double *__restrict__ d2, double lam,
                                                        double *__restrict__ binv, Coarse *__restrict__ coarse, Strides st,
-                                                       RowW rw) {
+                                                       RowW rw, int prec32) {
+    // prec32 = 1: store the inverse Cholesky factor Li (B^-1 = Li^T Li) in fp32 instead of the packed fp64 inverse:
+    // half the bytes of the largest array the CG update kernel streams, and Li^T (Li r) is symmetric positive
+    // definite for ANY rounding of Li, which is all a preconditioner has to be
     constexpr int S = Lay<DIM>::S, NA = Lay<DIM>::NA, NG = Lay<DIM>::NG;
     const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (j == 0)
@@ -1020,10 +1349,14 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
         }
     // packed lower triangle, entry q of vertex j at binv[q*n + j] (coalesced for the per-vertex lanes)
     double *out = binv + j;
+    float *out32 = (float *)binv + j;
     if (!ok) {
         int q = 0;
         for (int a = 0; a < S; ++a)
-            for (int b = 0; b <= a; ++b) out[(int64_t)(q++) * n] = a == b ? 1.0 / B[a][a] : 0.0;
+            for (int b = 0; b <= a; ++b) {
+                if (prec32) out32[(int64_t)(q++) * n] = a == b ? (float)(1.0 / sqrt(B[a][a])) : 0.0f;
+                else out[(int64_t)(q++) * n] = a == b ? 1.0 / B[a][a] : 0.0;
+            }
         return;
     }
     double Li[S][S];  // inverse of L (lower)
@@ -1038,6 +1371,11 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
         }
     }
     int q = 0;
+    if (prec32) {
+        for (int a = 0; a < S; ++a)
+            for (int b = 0; b <= a; ++b) out32[(int64_t)(q++) * n] = (float)Li[a][b];
+        return;
+    }
     for (int a = 0; a < S; ++a)
         for (int b = 0; b <= a; ++b) {
             double sum = 0.0;
@@ -1453,7 +1791,7 @@ struct FusedCg {
     int parity;  // which Scal::tmp slot holds r.z (see above); -1: the direction stage is NOT fused, r.z is Scal::rz
 };
 
-template <int DIM, bool FUSED, bool RICH>
+template <int DIM, bool FUSED, bool RICH, bool P32>
 __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s, const double *__restrict__ P,
                                                            const double *__restrict__ v, int64_t n,
                                                            double *__restrict__ x, double *__restrict__ r,
@@ -1533,16 +1871,34 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
             rj[e] = rj[e] - alpha * apj[e];
             zj[e] = 0.0;
         }
-        const double *B = binv + j;
-        int q = 0;
+        if constexpr (P32) {
+            // zb = Li^T (Li r): one pass over the rows of Li, every entry loaded once (fp32) and used twice (fp64 arithmetic)
+            const float *Lf = (const float *)binv + j;
+            float lrow[S * (S + 1) / 2];
 #pragma unroll
-        for (int a = 0; a < S; ++a)
+            for (int q = 0; q < S * (S + 1) / 2; ++q) lrow[q] = Lf[(int64_t)q * n];
+            int q = 0;
 #pragma unroll
-            for (int b = 0; b <= a; ++b) {
-                const double m = B[(int64_t)(q++) * n];
-                zj[a] += m * rj[b];
-                if (a != b) zj[b] += m * rj[a];
+            for (int a = 0; a < S; ++a) {
+                double ta = 0.0;
+#pragma unroll
+                for (int b = 0; b <= a; ++b) ta += (double)lrow[q + b] * rj[b];
+#pragma unroll
+                for (int b = 0; b <= a; ++b) zj[b] += (double)lrow[q + b] * ta;
+                q += a + 1;
             }
+        } else {
+            const double *B = binv + j;
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < S; ++a)
+#pragma unroll
+                for (int b = 0; b <= a; ++b) {
+                    const double m = B[(int64_t)(q++) * n];
+                    zj[a] += m * rj[b];
+                    if (a != b) zj[b] += m * rj[a];
+                }
+        }
         double z[NG][S];
         zmodes<DIM>(Pj_, vj_, z);
         if constexpr (RICH) poly_eval<DIM>(vj_, pb, phi);
@@ -2030,6 +2386,30 @@ static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const 
     if (int rc = allreduce(par, d.NG)) return rc;
     hipLaunchKernelGGL(tail_write_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)par.tot, 0, d.NG,
                        lam_d2 ? lam_d2 + d.n * d.S : nullptr, p_in ? p_in + d.n * d.S : nullptr, lam, out + d.n * d.S);
+    ICP_HIP_CHECK(hipGetLastError());
+    return ICP_OK;
+}
+
+// out = J^T W^2 J p + lam lam_d2 .* p on the local vertices, block partials of the tail sums (slots 0..NG) and of
+// p . out (slot 8) in w.partial -- what apply_J(sq = 1) followed by apply_JT(finish_tail = false) leaves, without
+// the row vector in between (fitrow_kernel + normal_kernel; ICP_NICP_FUSEDOP=0: the two-kernel pair through w.y)
+static int apply_A(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const double *P, const double *v, const double *c,
+                   bool compat, const double *p, const double *lam_d2, double lam, double *out) {
+    const char *env_op = getenv("ICP_NICP_FUSEDOP");
+    const bool fused_op = !(env_op && atoi(env_op) == 0);
+    if (!fused_op) {
+        if (int rc = apply_J(ctx, g, w, P, v, c, compat, p, w.y, 1)) return rc;
+        return apply_JT(ctx, g, w, par, P, v, c, compat, w.y, lam_d2, p, lam, out, false, false);
+    }
+    const int nbk = vgrid(g, g->n);
+    const double *rs = compat ? w.dd : w.pre;  // Q6
+    NICP_DISPATCH(g->dim, compat,
+                  hipLaunchKernelGGL((fitrow_kernel<D, C>), dim3(nbk), dim3(g->vb), 0, ctx->stream, p, g->nbr, g->wt, g->k, v, rs, g->n,
+                                     w.glob, c[0], w.y, w.st, w.rw));
+    NICP_DISPATCH(g->dim, compat,
+                  hipLaunchKernelGGL((normal_kernel<D, C>), dim3(nbk), dim3(g->vb), 0, ctx->stream, P, p, (const double *)w.y, v, rs,
+                                     g->rev_ptr, g->rev_i, g->rev_w, g->inc_ptr, g->inc_ent, g->inc_other, g->n, w.glob, c[0], c[1],
+                                     c[2], lam_d2, lam, out, w.partial, par.nown, w.st, w.rw));
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
 }
@@ -2541,6 +2921,9 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
     // partials); ICP_NICP_FUSED=0 / 1 forces the two single-block sum+logic launches / the fused kernels
     bool fused_enabled = g->vb == 64;
     if (const char *e = getenv("ICP_NICP_FUSED")) fused_enabled = atoi(e) != 0;
+    // vertex blocks of the preconditioner as an fp32 inverse Cholesky factor (default) or the packed fp64 inverse
+    bool prec32 = true;
+    if (const char *e = getenv("ICP_NICP_PREC32")) prec32 = atoi(e) != 0;
     bool use_graph = !par.sharded() && d.n >= 1024;
     if (const char *e = getenv("ICP_NICP_GRAPH")) use_graph = !par.sharded() && atoi(e) != 0;
     if (use_graph) {
@@ -2585,7 +2968,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                                              (const double *)g->wt, g->k, v, (const int32_t *)g->edges, (const int32_t *)g->rev_ptr,
                                              (const int32_t *)g->rev_ent, (const int32_t *)g->inc_ptr, (const int32_t *)g->inc_ent, d.n,
                                              (const Globals *)w.glob, c[0], c[1], c[2], (const double *)w.col2, (const double *)w.d2, lam,
-                                             w.binv, w.coarse, w.st, w.rw));
+                                             w.binv, w.coarse, w.st, w.rw, prec32 ? 1 : 0));
             ICP_HIP_CHECK(hipGetLastError());
             // The coarse matrix may lag: any symmetric positive (semi-)definite E^+ keeps the preconditioner valid, and
             // between consecutive LM steps of a long solve E barely moves, so it is rebuilt every `e_lag`-th linear
@@ -2597,8 +2980,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             for (int a = 0; rebuild_E && a < nz; ++a) {  // E[:, a] = Z^T (J^T J + lam D^2) z_a
                 if (g->dim == 3) hipLaunchKernelGGL(zcol_kernel<3>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z, w.st, w.pb);
                 else hipLaunchKernelGGL(zcol_kernel<2>, dim3(nbt), dim3(g->vb), 0, st, (const double *)x, v, d.n, a, w.z, w.st, w.pb);
-                if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.z, w.y, 1)) return rc;
-                if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.y, w.d2, w.z, lam, w.Ap, false, false)) return rc;
+                if (int rc = apply_A(ctx, g, w, par, x, v, c, compat, w.z, w.d2, lam, w.Ap)) return rc;
                 hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(1024), 0, st, (const double *)w.partial, nbj, ng_mask, par.tot, nm + 2);
                 if (g->dim == 3) hipLaunchKernelGGL(zt_kernel<3>, dim3(nbv), dim3(g->vb), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial, w.st, w.mom, w.pb);
                 else hipLaunchKernelGGL(zt_kernel<2>, dim3(nbv), dim3(g->vb), 0, st, (const double *)x, v, nown, (const double *)w.Ap, w.partial, w.st, w.mom, w.pb);
@@ -2642,8 +3024,8 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 FusedCg fa = {w.partial, nbj, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, fused ? parity : -1};
                 FusedCg fb = {w.partial2, nbv, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, parity};
                 double *upd_partial = fzu ? w.partial2 : w.partial;
-#define NICP_UPD(D, F) if (rich) NICP_UPD2(D, F, true); else NICP_UPD2(D, F, false)
-#define NICP_UPD2(D, F, R) hipLaunchKernelGGL((cg_update_prec_kernel<D, F, R>), dim3(nbv), dim3(g->vb), 0, st, w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, upd_partial, nown, w.st, (const Coarse *)w.coarse, fa, w.mom, w.pb)
+#define NICP_UPD(D, F) if (rich) { if (prec32) NICP_UPD2(D, F, true, true); else NICP_UPD2(D, F, true, false); } else { if (prec32) NICP_UPD2(D, F, false, true); else NICP_UPD2(D, F, false, false); }
+#define NICP_UPD2(D, F, R, Q) hipLaunchKernelGGL((cg_update_prec_kernel<D, F, R, Q>), dim3(nbv), dim3(g->vb), 0, st, w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, upd_partial, nown, w.st, (const Coarse *)w.coarse, fa, w.mom, w.pb)
 #define NICP_DIR(D, F) hipLaunchKernelGGL((cg_dir_prec_kernel<D, F>), dim3(nbt), dim3(g->vb), 0, st, w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown, w.st, fb, w.pb)
                 if (g->dim == 3) { if (fzu) { NICP_UPD(3, true); } else { NICP_UPD(3, false); } }
                 else { if (fzu) { NICP_UPD(2, true); } else { NICP_UPD(2, false); } }
@@ -2674,8 +3056,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             // path can replay kCgChunk iterations as one hipGraph (6 launches each, launch-bound on small meshes).
             auto cg_iterations = [&](int count) -> int {
                 for (int k = 0; k < count; ++k) {
-                    if (int rc = apply_J(ctx, g, w, x, v, c, compat, w.pcg, w.y, 1)) return rc;
-                    if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.y, w.lamd2, w.pcg, 1.0, w.Ap, false, false)) return rc;
+                    if (int rc = apply_A(ctx, g, w, par, x, v, c, compat, w.pcg, w.lamd2, 1.0, w.Ap)) return rc;
                     if (fused || mixed) {
                         // the update kernel sums the partials and derives alpha itself
                     } else if (!par.sharded()) {

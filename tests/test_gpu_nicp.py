@@ -314,6 +314,43 @@ def test_cg_graph_replay_is_bit_identical(mods, monkeypatch):
     assert np.array_equal(Pa.cpu().numpy(), Pb.cpu().numpy())
 
 
+@pytest.mark.parametrize("case", ["corrected", "compat", "weighted", "row2d", "row2d_compat"])
+def test_fused_operator_is_bit_identical(mods, monkeypatch, case):
+    """The fused CG operator (fitrow_kernel + normal_kernel: no J p row vector in memory) forms every row value and
+    every sum by the same operations in the same order as jp_kernel -> jtu_kernel (ICP_NICP_FUSEDOP=0): parameters,
+    energies and iteration counts must agree bit for bit -- 3-D and 2-D, compat quirks, row weights + landmarks."""
+    nic = mods["nicp"]
+    rng = np.random.default_rng(5)
+    if case.startswith("row2d"):
+        x = np.linspace(0, 2 * np.pi, 1500)
+        v = np.stack([x, np.sin(x) * (0.5 + x / 6)], 1) @ orc.rot2(0.3) + np.array([2.0, 3.5])
+        edges = np.stack([np.arange(1499), np.arange(1, 1500)], 1).astype(np.int32)
+        tgt = v + 0.05 * rng.standard_normal(v.shape)
+    else:
+        v, edges, tgt = orc.make_grid_mesh(40, 36, seed=11)
+    w = nic.knn_weights(v)
+    nn = tgt[c_oracle.match_idx(v, tgt)[0]]
+    P0 = nic.initial_params(len(v), v.shape[1])
+    P0 = P0 + 0.01 * rng.standard_normal(P0.shape)          # R != I, A != I: every term of the operator is live
+    if case == "weighted":
+        w.set_weights(edges, rng.uniform(0.2, 2.0, len(v)), rng.uniform(0.5, 1.5, len(v)), rng.uniform(0.3, 3.0, len(edges)))
+        lm = rng.permutation(len(v))[:50].astype(np.int32)
+        w.set_landmarks(edges, lm, v[lm] + 0.02, 5.0)
+    compat = case.endswith("compat")
+    opts = dict(max_lm_iters=3, cg_tol=1e-8, max_cg_iters=400)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ICP_NICP_FUSEDOP", mode)
+        for coarse in ("1", "10" if v.shape[1] == 3 else "6"):
+            monkeypatch.setenv("ICP_NICP_COARSE", coarse)
+            P, st = nic.solve(P0, w, v, edges, nn, C, compat=compat, opts=opts)
+            out[mode, coarse] = (P.cpu().numpy(), st)
+    for coarse in ("1", "10" if v.shape[1] == 3 else "6"):
+        a, b = out["0", coarse], out["1", coarse]
+        assert a[1]["cg_iters"] >= 50 and a[1] == b[1]
+        assert np.array_equal(a[0], b[0])
+
+
 def test_mesh_beyond_the_old_partial_cap(mods):
     """640 000 vertices (the block-partial buffers used to cap meshes at 2048 blocks = 524 288 vertices):
     <Jp, Jq> == <p, J^T J q>, and a bounded solve lowers the energy, deterministically."""
