@@ -186,6 +186,48 @@ __device__ __forceinline__ void block_reduce_partials(const double *__restrict__
     __syncthreads();
 }
 
+// One rotation of the one-sided Jacobi iteration on columns (P, Q) of A (and of V).  P and Q are template
+// parameters and every loop below has constant bounds: A, V and U live in registers.  (With run-time column indices
+// the compiler kept the matrices in scratch memory, 128 bytes per lane, and every access of this serial chain paid a
+// memory round trip: the solve took 16 us on its one lane.)
+template <int DIM, int P, int Q>
+__device__ __forceinline__ bool jacobi_pair(double (&A)[DIM][DIM], double (&V)[DIM][DIM]) {
+    double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) {
+        alpha += A[r][P] * A[r][P];
+        beta += A[r][Q] * A[r][Q];
+        gamma += A[r][P] * A[r][Q];
+    }
+    // columns orthogonal to rounding: |gamma| <= 2.3e-16 sqrt(alpha beta), tested on the squares
+    if (gamma == 0.0 || gamma * gamma <= 5.29e-32 * (alpha * beta)) return false;
+    // tan of the rotation angle: t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (beta - alpha) / (2 gamma),
+    // multiplied through by |2 gamma| (one square root and one division on this serial path, not two and two)
+    const double g2 = 2.0 * gamma, dlt = beta - alpha;
+    const double tt = ((dlt >= 0) == (g2 >= 0) ? fabs(g2) : -fabs(g2)) / (fabs(dlt) + sqrt(g2 * g2 + dlt * dlt));
+    const double c = rsqrt(1.0 + tt * tt), s = c * tt;
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) {
+        const double ap = A[r][P], aq = A[r][Q];
+        A[r][P] = c * ap - s * aq;
+        A[r][Q] = s * ap + c * aq;
+        const double vp = V[r][P], vq = V[r][Q];
+        V[r][P] = c * vp - s * vq;
+        V[r][Q] = s * vp + c * vq;
+    }
+    return true;
+}
+
+// 3-D, rank 2: the missing left vector J completes U to a frame of V's handedness (LAPACK's choice there is arbitrary;
+// SURVEY.md section 7 "SVD degeneracy")
+template <int J>
+__device__ __forceinline__ void complete_column3(double (&U)[3][3], double sg) {
+    constexpr int a = (J + 1) % 3, b = (J + 2) % 3;
+    U[0][J] = sg * (U[1][a] * U[2][b] - U[2][a] * U[1][b]);
+    U[1][J] = sg * (U[2][a] * U[0][b] - U[0][a] * U[2][b]);
+    U[2][J] = sg * (U[0][a] * U[1][b] - U[1][a] * U[0][b]);
+}
+
 // One-sided Jacobi SVD of a DIMxDIM matrix; returns the reference's R = (U VT)^T = V U^T.
 template <int DIM>
 __device__ void polar_rotation(const double (&W)[DIM][DIM], double (&R)[DIM][DIM]) {
@@ -193,85 +235,90 @@ __device__ void polar_rotation(const double (&W)[DIM][DIM], double (&R)[DIM][DIM
     // R does not depend on the scale of W: bring the largest entry to [1, 2) by an exact power of two, so that the
     // products of squared column norms below can neither overflow nor underflow whatever the units of the clouds
     double wmax = 0.0;
+#pragma unroll
     for (int a = 0; a < DIM; ++a)
+#pragma unroll
         for (int b = 0; b < DIM; ++b) wmax = fmax(wmax, fabs(W[a][b]));
     int ex = 0;
     if (wmax > 0.0 && wmax <= 1.7e308) (void)frexp(wmax, &ex);
+#pragma unroll
     for (int a = 0; a < DIM; ++a)
+#pragma unroll
         for (int b = 0; b < DIM; ++b) {
             A[a][b] = ldexp(W[a][b], 1 - ex);
             V[a][b] = a == b ? 1.0 : 0.0;
         }
     for (int sweep = 0; sweep < 60; ++sweep) {
-        bool rotated = false;
-        for (int p = 0; p < DIM - 1; ++p)
-            for (int q = p + 1; q < DIM; ++q) {
-                double alpha = 0, beta = 0, gamma = 0;
-                for (int r = 0; r < DIM; ++r) {
-                    alpha += A[r][p] * A[r][p];
-                    beta += A[r][q] * A[r][q];
-                    gamma += A[r][p] * A[r][q];
-                }
-                // columns orthogonal to rounding: |gamma| <= 2.3e-16 sqrt(alpha beta), tested on the squares
-                if (gamma == 0.0 || gamma * gamma <= 5.29e-32 * (alpha * beta)) continue;
-                rotated = true;
-                // tan of the rotation angle: t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (beta - alpha) / (2 gamma),
-                // multiplied through by |2 gamma| (one square root and one division on this serial path, not two and two)
-                const double g2 = 2.0 * gamma, dlt = beta - alpha;
-                const double tt = ((dlt >= 0) == (g2 >= 0) ? fabs(g2) : -fabs(g2)) / (fabs(dlt) + sqrt(g2 * g2 + dlt * dlt));
-                const double c = rsqrt(1.0 + tt * tt), s = c * tt;
-                for (int r = 0; r < DIM; ++r) {
-                    const double ap = A[r][p], aq = A[r][q];
-                    A[r][p] = c * ap - s * aq;
-                    A[r][q] = s * ap + c * aq;
-                    const double vp = V[r][p], vq = V[r][q];
-                    V[r][p] = c * vp - s * vq;
-                    V[r][q] = s * vp + c * vq;
-                }
-            }
+        bool rotated = jacobi_pair<DIM, 0, 1>(A, V);
+        if constexpr (DIM == 3) {
+            rotated |= jacobi_pair<DIM, 0, 2>(A, V);
+            rotated |= jacobi_pair<DIM, 1, 2>(A, V);
+        }
         if (!rotated) break;
     }
     // U[:,j] = A[:,j]/sigma_j.  Rank-deficient W: the missing left vectors are completed to a
     // right-handed frame (LAPACK's choice there is arbitrary; SURVEY.md section 7 "SVD degeneracy").
     double U[DIM][DIM], sig[DIM], smax = 0;
+#pragma unroll
     for (int j = 0; j < DIM; ++j) {
         double s2 = 0;
+#pragma unroll
         for (int r = 0; r < DIM; ++r) s2 += A[r][j] * A[r][j];
         sig[j] = sqrt(s2);
         smax = sig[j] > smax ? sig[j] : smax;
     }
     bool ok[DIM];
     int nok = 0;
+#pragma unroll
     for (int j = 0; j < DIM; ++j) {
         ok[j] = sig[j] > 1e-300 && sig[j] > 1e-14 * smax;
         nok += ok[j];
+#pragma unroll
         for (int r = 0; r < DIM; ++r) U[r][j] = ok[j] ? A[r][j] / sig[j] : 0.0;
     }
     if (nok < DIM) {
-        if (DIM == 3 && nok == 2) {
-            int j = !ok[0] ? 0 : (!ok[1] ? 1 : 2), a = (j + 1) % 3, b = (j + 2) % 3;
-            // u_j = u_a x u_b and v_j = v_a x v_b would keep both frames right-handed; V is
-            // already orthonormal, so only U needs completing (sign follows det V).
-            double detV = V[0][0] * (V[1][1] * V[2][2] - V[1][2] * V[2][1]) - V[0][1] * (V[1][0] * V[2][2] - V[1][2] * V[2][0]) +
-                          V[0][2] * (V[1][0] * V[2][1] - V[1][1] * V[2][0]);
-            double sg = detV < 0 ? -1.0 : 1.0;
-            U[0][j] = sg * (U[1][a] * U[2][b] - U[2][a] * U[1][b]);
-            U[1][j] = sg * (U[2][a] * U[0][b] - U[0][a] * U[2][b]);
-            U[2][j] = sg * (U[0][a] * U[1][b] - U[1][a] * U[0][b]);
-        } else if (DIM == 2 && nok == 1) {
-            int j = ok[0] ? 1 : 0, a = 1 - j;
-            double detV = V[0][0] * V[1][1] - V[0][1] * V[1][0];
-            double sg = (detV < 0 ? -1.0 : 1.0) * (j == 1 ? 1.0 : -1.0);
-            U[0][j] = -sg * U[1][a];
-            U[1][j] = sg * U[0][a];
+        if constexpr (DIM == 3) {
+            if (nok == 2) {
+                // u_j = u_a x u_b and v_j = v_a x v_b would keep both frames right-handed; V is
+                // already orthonormal, so only U needs completing (sign follows det V).
+                const double detV = V[0][0] * (V[1][1] * V[2][2] - V[1][2] * V[2][1]) - V[0][1] * (V[1][0] * V[2][2] - V[1][2] * V[2][0]) +
+                                    V[0][2] * (V[1][0] * V[2][1] - V[1][1] * V[2][0]);
+                const double sg = detV < 0 ? -1.0 : 1.0;
+                if (!ok[0]) complete_column3<0>(U, sg);
+                else if (!ok[1]) complete_column3<1>(U, sg);
+                else complete_column3<2>(U, sg);
+            } else {
+#pragma unroll
+                for (int a = 0; a < DIM; ++a)
+#pragma unroll
+                    for (int b = 0; b < DIM; ++b) U[a][b] = V[a][b];  // W ~ 0: R = I
+            }
         } else {
-            for (int a = 0; a < DIM; ++a)
-                for (int b = 0; b < DIM; ++b) U[a][b] = V[a][b];  // W ~ 0: R = I
+            if (nok == 1) {
+                const double detV = V[0][0] * V[1][1] - V[0][1] * V[1][0];
+                if (ok[0]) {   // complete column 1 from column 0
+                    const double sg = detV < 0 ? -1.0 : 1.0;
+                    U[0][1] = -sg * U[1][0];
+                    U[1][1] = sg * U[0][0];
+                } else {       // complete column 0 from column 1
+                    const double sg = detV < 0 ? 1.0 : -1.0;
+                    U[0][0] = -sg * U[1][1];
+                    U[1][0] = sg * U[0][1];
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < DIM; ++a)
+#pragma unroll
+                    for (int b = 0; b < DIM; ++b) U[a][b] = V[a][b];  // W ~ 0: R = I
+            }
         }
     }
+#pragma unroll
     for (int a = 0; a < DIM; ++a)
+#pragma unroll
         for (int b = 0; b < DIM; ++b) {
             double r = 0;
+#pragma unroll
             for (int j = 0; j < DIM; ++j) r += V[a][j] * U[b][j];
             R[a][b] = r;
         }
@@ -298,9 +345,18 @@ __global__ __launch_bounds__(RB) void reduce_solve_kernel(const double *__restri
                                                           double *__restrict__ t_out, const int32_t *__restrict__ done) {
     if (done && *done) return;
     __shared__ double tot[kSumSlots];
+    // the shifts are fetched before the sums they are combined with (one memory round trip less on the serial tail)
+    double csr[DIM], ctr[DIM];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            csr[c] = cs[c];
+            ctr[c] = ct[c];
+        }
+    }
     block_reduce_partials(partial, nb, tot);
     if (threadIdx.x < kSumSlots) sums_out[threadIdx.x] = tot[threadIdx.x];
-    if (threadIdx.x == 0) kabsch_from_sums<DIM>(tot, cs, ct, R_out, t_out);
+    if (threadIdx.x == 0) kabsch_from_sums<DIM>(tot, csr, ctr, R_out, t_out);
 }
 
 template <int DIM>
@@ -405,19 +461,7 @@ __global__ void rigid_init_kernel(RigidState *st) {
     st->iters = 0;
 }
 
-// end of one iteration: icp_3d.py:107,114-117
-__global__ void rigid_step_kernel(RigidState *st, double tol, int use_tol, double *err_hist) {
-    if (st->done) return;
-    const double e = st->err_prev;
-    const double err = st->sums[0];
-    st->err = err;
-    st->err_prev = err;
-    if (err_hist) err_hist[st->iters] = err;
-    st->iters += 1;
-    if (use_tol && (e - err) < tol) st->done = 1;
-}
-
-// fused: final reduction of the error partials + the end-of-iteration bookkeeping
+// final reduction of the error partials + the end-of-iteration bookkeeping (icp_3d.py:107,114-117)
 __global__ __launch_bounds__(RB) void reduce_step_kernel(const double *__restrict__ partial, int nb, RigidState *st,
                                                          double tol, int use_tol, double *err_hist) {
     if (st->done) return;

@@ -1800,30 +1800,66 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
                                                            double *__restrict__ partial, int64_t nown, Strides st,
                                                            const Coarse *__restrict__ coarse, FusedCg f,
                                                            double *__restrict__ mom, PolyBasis pb) {
-    constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
+    constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG, TRI = S * (S + 1) / 2;
     const int64_t j = (int64_t)vblock() * blockDim.x + threadIdx.x;
     double acc[2 + NG], phi[MAXPOLY];
     for (int k = 0; k < 2 + NG; ++k) acc[k] = 0.0;
     for (int m = 0; m < MAXPOLY; ++m) phi[m] = 0.0;
+    // The vertex's own blocks do not depend on alpha: their loads are issued FIRST, so the memory latency of the body
+    // overlaps the (fused) reduction prologue below instead of following it (10 k vertices: both are latency chains).
+    // Every load first, every store last: with run-time strides the compiler cannot tell x[o_e] from x[o_e'] and would
+    // otherwise wait for each store before the next load (12 round trips in a row).
+    double xj[S], rj[S], pj[S], apj[S], zj[S], Pj_[S], vj_[DIM];
+    float lrow[P32 ? TRI : 1];
+    const bool mine = j < nown;
+    if (mine) {
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            const int64_t o = j * st.pj + e * st.pe;
+            xj[e] = x[o];
+            rj[e] = r[o];
+            pj[e] = p[o];
+            apj[e] = Ap[o];
+            Pj_[e] = P[o];
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) vj_[c] = v[j * st.vj + c * st.vc];
+        if constexpr (P32) {
+            const float *Lf = (const float *)binv + j;
+#pragma unroll
+            for (int q = 0; q < TRI; ++q) lrow[q] = Lf[(int64_t)q * n];
+        }
+    }
     double alpha_blk = 0.0;
     bool stop_blk;
     if constexpr (FUSED) {
         __shared__ double tot_s[kSumSlots];
         __shared__ double alpha_sh;
         __shared__ int stop_sh;
+        // the scalars of the alpha logic, fetched before the sums they are combined with (thread 0 of every block)
+        int stop0 = 0;
+        double rz0 = 0.0, lt0[NG], pt0[NG];
+        if (threadIdx.x == 0) {
+            stop0 = s->stop;
+            rz0 = f.parity >= 0 ? s->tmp[f.parity] : s->rz;
+            for (int k = 0; k < NG; ++k) {
+                lt0[k] = f.lamd2_tail[k];
+                pt0[k] = f.p_tail[k];
+            }
+        }
         block_rows_sum_lds<((1u << NG) - 1u) | (1u << 8)>(f.in_partial, f.nb, tot_s);
         __syncthreads();
         if (threadIdx.x == 0) {  // alpha_logic, by every block for itself
-            int stop = s->stop;
+            int stop = stop0;
             double alpha = 0.0;
             if (!stop) {
                 double pap = tot_s[8], apt[NG];
                 for (int k = 0; k < NG; ++k) {
-                    const double val = tot_s[k] + f.lamd2_tail[k] * f.p_tail[k];
+                    const double val = tot_s[k] + lt0[k] * pt0[k];
                     apt[k] = val;
-                    pap += val * f.p_tail[k];
+                    pap += val * pt0[k];
                 }
-                alpha = pap > 0 ? (f.parity >= 0 ? s->tmp[f.parity] : s->rz) / pap : 0.0;
+                alpha = pap > 0 ? rz0 / pap : 0.0;
                 if (!(pap > 0)) stop = 2;  // breakdown (non-positive curvature / NaN)
                 if (blockIdx.x == 0) {
                     s->pAp = pap;
@@ -1832,7 +1868,7 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
                     for (int k = 0; k < NG; ++k) {
                         f.Ap_tail[k] = apt[k];
                         if (stop) continue;
-                        f.x_tail[k] += alpha * f.p_tail[k];  // the tail's share of the update (coarse_logic does it when unfused)
+                        f.x_tail[k] += alpha * pt0[k];  // the tail's share of the update (coarse_logic does it when unfused)
                         const double rt = f.r_tail[k] - alpha * apt[k];
                         f.r_tail[k] = rt;
                         f.zb_tail[k] = rt * coarse->tail_minv[k];
@@ -1849,22 +1885,8 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
         stop_blk = s->stop != 0;
         alpha_blk = s->alpha;
     }
-    if (j < nown && !stop_blk) {
+    if (mine && !stop_blk) {
         const double alpha = alpha_blk;
-        // every load first, every store last: with run-time strides the compiler cannot tell x[o_e] from
-        // x[o_e'] and would otherwise wait for each store before the next load (12 round trips in a row)
-        double xj[S], rj[S], pj[S], apj[S], zj[S], Pj_[S], vj_[DIM];
-#pragma unroll
-        for (int e = 0; e < S; ++e) {
-            const int64_t o = j * st.pj + e * st.pe;
-            xj[e] = x[o];
-            rj[e] = r[o];
-            pj[e] = p[o];
-            apj[e] = Ap[o];
-            Pj_[e] = P[o];
-        }
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) vj_[c] = v[j * st.vj + c * st.vc];
 #pragma unroll
         for (int e = 0; e < S; ++e) {
             xj[e] += alpha * pj[e];
@@ -1873,10 +1895,6 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
         }
         if constexpr (P32) {
             // zb = Li^T (Li r): one pass over the rows of Li, every entry loaded once (fp32) and used twice (fp64 arithmetic)
-            const float *Lf = (const float *)binv + j;
-            float lrow[S * (S + 1) / 2];
-#pragma unroll
-            for (int q = 0; q < S * (S + 1) / 2; ++q) lrow[q] = Lf[(int64_t)q * n];
             int q = 0;
 #pragma unroll
             for (int a = 0; a < S; ++a) {
@@ -1947,19 +1965,49 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, c
     const int nm = FUSED ? NG : NG * pb.M;  // vertex-mode columns of Z (the fused kernels serve the plain space only)
     __shared__ double y_s[NZMAX];
     double beta;
+    // the vertex's own blocks first: their latency overlaps the (fused) reduction prologue (see cg_update_prec_kernel)
+    const int64_t j = (int64_t)vblock() * blockDim.x + threadIdx.x;
+    double Pj_[S], vj_[DIM], zbj[S], pj[S];
+    const bool mine = j < n && j < nown;
+    if (mine) {
+#pragma unroll
+        for (int e = 0; e < S; ++e) {  // loads first, stores last (see cg_update_prec_kernel)
+            const int64_t o = j * st.pj + e * st.pe;
+            Pj_[e] = P[o];
+            zbj[e] = zb[o];
+            pj[e] = p[o];
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) vj_[c] = v[j * st.vj + c * st.vc];
+    }
     if constexpr (FUSED) {
         constexpr int nz = 2 * NG;
         __shared__ double tot_s[kSumSlots], ztr_s[NZMAX], acc_s[2];
         __shared__ double beta_sh;
         __shared__ int stop_sh;
+        // scalars and the rows of E^-1, fetched before the sums they meet
+        int stop0 = 0;
+        double rt0[NG], zt0[NG], rzold0 = 0.0, tol20 = 0.0, rr00 = 0.0, erow[2 * NG];
+        if (threadIdx.x == 0) {
+            stop0 = s->stop;
+            rzold0 = s->tmp[f.parity];
+            tol20 = coarse->tol2;
+            rr00 = s->rr0;
+            for (int k = 0; k < NG; ++k) {
+                rt0[k] = f.r_tail[k];
+                zt0[k] = f.zb_tail[k];
+            }
+        }
+        if (threadIdx.x < nz)
+            for (int b = 0; b < nz; ++b) erow[b] = coarse->Einv[threadIdx.x * nz + b];
         block_rows_sum_lds<(1u << (2 + NG)) - 1u>(f.in_partial, f.nb, tot_s);
         __syncthreads();
         if (threadIdx.x == 0) {  // coarse_logic, by every block for itself (the tails were advanced by the update kernel)
-            const int stop = s->stop;
+            const int stop = stop0;
             if (!stop) {
                 double rz = tot_s[0], rr = tot_s[1];
                 for (int k = 0; k < NG; ++k) {
-                    const double rt = f.r_tail[k], zt = f.zb_tail[k];
+                    const double rt = rt0[k], zt = zt0[k];
                     rz += rt * zt;
                     rr += rt * rt;
                     ztr_s[k] = tot_s[2 + k];
@@ -1973,7 +2021,7 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, c
         __syncthreads();
         if (!stop_sh && threadIdx.x < nz) {
             double y = 0.0;
-            for (int b = 0; b < nz; ++b) y += coarse->Einv[threadIdx.x * nz + b] * ztr_s[b];
+            for (int b = 0; b < nz; ++b) y += erow[b] * ztr_s[b];
             y_s[threadIdx.x] = y;
         }
         __syncthreads();
@@ -1981,8 +2029,8 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, c
             double rz = acc_s[0];
             const double rr = acc_s[1];
             for (int a = 0; a < nz; ++a) rz += ztr_s[a] * y_s[a];
-            const double bt = rz / s->tmp[f.parity];
-            const bool done = !(rr > coarse->tol2 * s->rr0);
+            const double bt = rz / rzold0;
+            const bool done = !(rr > tol20 * rr00);
             if (blockIdx.x == 0) {
                 s->rz_new = rz;
                 s->rr = rr;
@@ -2004,19 +2052,9 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, c
         for (int i = threadIdx.x; i < nm + NG; i += blockDim.x) y_s[i] = coarse->y[i];
         __syncthreads();
     }
-    const int64_t j = (int64_t)vblock() * blockDim.x + threadIdx.x;
     if (j < n) {
         if (j >= nown) return;  // halo copy
-        double z[NG][S], Pj_[S], vj_[DIM], zbj[S], pj[S], yk[NG];
-#pragma unroll
-        for (int e = 0; e < S; ++e) {  // loads first, stores last (see cg_update_prec_kernel)
-            const int64_t o = j * st.pj + e * st.pe;
-            Pj_[e] = P[o];
-            zbj[e] = zb[o];
-            pj[e] = p[o];
-        }
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) vj_[c] = v[j * st.vj + c * st.vc];
+        double z[NG][S], yk[NG];
 #pragma unroll
         for (int k = 0; k < NG; ++k) yk[k] = y_s[k];
         if (!FUSED && pb.M > 1) {  // y_k(j) = sum_m y[m*NG + k] phi_m(v_j)
