@@ -313,6 +313,16 @@ def main():
         try:
             extra["nicp_c3"] = {"compat": nicp_c3(ctx, True), "corrected": nicp_c3(ctx, False),
                                 "note": "config C3, whole outer loop per mode; NICP CG kernels: see DESIGN.md 3.3 and profiles/"}
+            # the CG iteration timed live with HIP events on the launch stream (nicp_profile_cg): C3 size with the plain and the
+            # enriched coarse space, and C5 size (200k vertices) on this one GPU; roofline = SURVEY 8(d)'s 0.86 kB per vertex per
+            # iteration over the iteration as the solver runs it, and each kernel's own minimal bytes over its launch
+            sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+            import cg_profile
+            extra["nicp_cg"] = {"c3_10k_plain_coarse": cg_profile.profile(100, 100, 100, 1, ctx),
+                                "c3_10k_enriched_coarse": cg_profile.profile(100, 100, 100, 10, ctx),
+                                "c5_size_200k_one_gpu": cg_profile.profile(448, 448, 100, 1, ctx),
+                                "note": "us_iteration: hipGraph replay, as nicp_solve runs it; us_kernel: plain launches with an event "
+                                        "after each (kernel + launch gap, an upper bound on the kernel)"}
         except Exception as e:      # the rigid line must survive an NICP failure
             extra["nicp_c3"] = {"error": repr(e)}
 

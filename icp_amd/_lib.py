@@ -65,6 +65,7 @@ _SIGNATURES = {
     "nicp_jvp": [c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_dp, c_dp],
     "nicp_jtvp": [c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_dp, c_dp],
     "nicp_solve": [c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_dp, c_dp],
+    "nicp_profile_cg": [c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_int, c_dp],
     "nicp_solve_dist": [c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32, c_dp, c_dp, c_dp],
     "nicp_run": [c_dp, c_dp, c_dp, c_dp, c_dp, c_i64, c_dbl, c_int, c_dp, c_u32, c_dp, c_dp, c_dp, c_dp],
 }
@@ -80,6 +81,12 @@ class SolveStats(ctypes.Structure):
     """nicp_solve_stats of include/icp_hip.h"""
     _fields_ = [("err", c_dbl), ("err0", c_dbl), ("lm_iters", c_int), ("cg_iters", c_int), ("nfev", c_int),
                 ("info", c_int), ("graph_launches", c_int)]
+
+
+class CgProfile(ctypes.Structure):
+    """nicp_cg_profile of include/icp_hip.h"""
+    _fields_ = [("iterations", c_int), ("launches_per_iteration", c_int), ("graph_replay", c_int), ("coarse_columns", c_int),
+                ("vertices", c_i64), ("edges", c_i64), ("us_iteration", c_dbl), ("us_kernel", c_dbl * 6)]
 
 
 NICP_REFERENCE_COMPAT = 1

@@ -2432,11 +2432,12 @@ static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const 
 // p . out (slot 8) in w.partial -- what apply_J(sq = 1) followed by apply_JT(finish_tail = false) leaves, without
 // the row vector in between (fitrow_kernel + normal_kernel; ICP_NICP_FUSEDOP=0: the two-kernel pair through w.y)
 static int apply_A(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const double *P, const double *v, const double *c,
-                   bool compat, const double *p, const double *lam_d2, double lam, double *out) {
+                   bool compat, const double *p, const double *lam_d2, double lam, double *out, hipEvent_t mid = nullptr) {
     const char *env_op = getenv("ICP_NICP_FUSEDOP");
     const bool fused_op = !(env_op && atoi(env_op) == 0);
     if (!fused_op) {
         if (int rc = apply_J(ctx, g, w, P, v, c, compat, p, w.y, 1)) return rc;
+        if (mid) (void)hipEventRecord(mid, ctx->stream);
         return apply_JT(ctx, g, w, par, P, v, c, compat, w.y, lam_d2, p, lam, out, false, false);
     }
     const int nbk = vgrid(g, g->n);
@@ -2444,6 +2445,7 @@ static int apply_A(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const d
     NICP_DISPATCH(g->dim, compat,
                   hipLaunchKernelGGL((fitrow_kernel<D, C>), dim3(nbk), dim3(g->vb), 0, ctx->stream, p, g->nbr, g->wt, g->k, v, rs, g->n,
                                      w.glob, c[0], w.y, w.st, w.rw));
+    if (mid) (void)hipEventRecord(mid, ctx->stream);  // nicp_profile_cg: boundary between the two kernels
     NICP_DISPATCH(g->dim, compat,
                   hipLaunchKernelGGL((normal_kernel<D, C>), dim3(nbk), dim3(g->vb), 0, ctx->stream, P, p, (const double *)w.y, v, rs,
                                      g->rev_ptr, g->rev_i, g->rev_w, g->inc_ptr, g->inc_ent, g->inc_other, g->n, w.glob, c[0], c[1],
@@ -2851,7 +2853,7 @@ static int relayout(icp_ctx *ctx, const double *src, int64_t sj, int64_t se, dou
 
 static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, double *P_inout, const double *v_ext,
                       const double *nn_ext, const double *c3_host, unsigned flags, const nicp_solve_opts *opts_in,
-                      nicp_solve_stats *stats_out) {
+                      nicp_solve_stats *stats_out, nicp_cg_profile *prof = nullptr) {
     {   // A/B switch for the block order of the CG kernels (vblock): written only when the variable is set
         static const int run_env = getenv("ICP_NICP_RUN") ? atoi(getenv("ICP_NICP_RUN")) : -1;
         if (run_env >= 0) ICP_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_nicp_run), &run_env, sizeof(int)));
@@ -3056,6 +3058,10 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             const bool mixed = !par.sharded() && fused_enabled && rich;   // enriched space: alpha stage fused, coarse stage its own launch
             // slots of the update kernel's partial rows that the sums read: r.zb, r.r (+ the NG plain moments)
             const unsigned upd_mask = rich ? 0x3u : (1u << (2 + d.NG)) - 1u;
+            hipEvent_t *pev = nullptr;  // nicp_profile_cg: events after every launch of an iteration
+            auto mark = [&](int k) {
+                if (pev) (void)hipEventRecord(pev[k], st);
+            };
             auto precondition = [&](int init, int parity) -> int {
                 const bool fz = fused && !init;            // both stages fused (plain coarse space)
                 const bool fzu = (fused || mixed) && !init;  // the update kernel derives alpha itself
@@ -3067,6 +3073,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
 #define NICP_DIR(D, F) hipLaunchKernelGGL((cg_dir_prec_kernel<D, F>), dim3(nbt), dim3(g->vb), 0, st, w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown, w.st, fb, w.pb)
                 if (g->dim == 3) { if (fzu) { NICP_UPD(3, true); } else { NICP_UPD(3, false); } }
                 else { if (fzu) { NICP_UPD(2, true); } else { NICP_UPD(2, false); } }
+                mark(4);
                 if (fz) {
                     // sums + coarse solve happen inside the direction kernel
                 } else if (!par.sharded()) {
@@ -3080,8 +3087,10 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                     hipLaunchKernelGGL(cg_coarse_logic_kernel, dim3(1), dim3(128), 0, st, (const double *)par.tot, d.NG, x_tail, r_tail, zb_tail,
                                        (const double *)p_tail, (const double *)Ap_tail, w.coarse, w.scal, init, nm);
                 }
+                mark(5);
                 if (g->dim == 3) { if (fz) NICP_DIR(3, true); else NICP_DIR(3, false); }
                 else { if (fz) NICP_DIR(2, true); else NICP_DIR(2, false); }
+                mark(6);
 #undef NICP_UPD
 #undef NICP_UPD2
 #undef NICP_DIR
@@ -3094,7 +3103,9 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             // path can replay kCgChunk iterations as one hipGraph (6 launches each, launch-bound on small meshes).
             auto cg_iterations = [&](int count) -> int {
                 for (int k = 0; k < count; ++k) {
-                    if (int rc = apply_A(ctx, g, w, par, x, v, c, compat, w.pcg, w.lamd2, 1.0, w.Ap)) return rc;
+                    mark(0);
+                    if (int rc = apply_A(ctx, g, w, par, x, v, c, compat, w.pcg, w.lamd2, 1.0, w.Ap, pev ? pev[1] : nullptr)) return rc;
+                    mark(2);
                     if (fused || mixed) {
                         // the update kernel sums the partials and derives alpha itself
                     } else if (!par.sharded()) {
@@ -3106,7 +3117,16 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                         hipLaunchKernelGGL(cg_alpha_logic_kernel, dim3(1), dim3(64), 0, st, (const double *)par.tot, d.NG, lamd2_tail,
                                            (const double *)p_tail, 1.0, Ap_tail, w.scal);
                     }
+                    mark(3);
                     if (int rc = precondition(0, k & 1)) return rc;
+                    if (pev) {  // one iteration at a time: read its seven time stamps
+                        ICP_HIP_CHECK(hipEventSynchronize(pev[6]));
+                        for (int q = 0; q < 6; ++q) {
+                            float ms = 0.f;
+                            ICP_HIP_CHECK(hipEventElapsedTime(&ms, pev[q], pev[q + 1]));
+                            prof->us_kernel[q] += 1e3 * ms;
+                        }
+                    }
                 }
                 ICP_HIP_CHECK(hipGetLastError());
                 return ICP_OK;
@@ -3136,6 +3156,54 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                     cg.exec = nullptr;
                     cg.failed = true;
                 }
+            }
+            if (prof) {
+                // Measurement only (nicp_profile_cg): the stop tolerance is zeroed so that no kernel takes its early
+                // exit, then (1) `iterations` CG iterations as plain launches with an event after every launch and
+                // (2) the same number the way the solver runs them (hipGraph replay where enabled) between two events.
+                const int iters = std::max(2, prof->iterations) & ~1;  // even: the fused kernels alternate a parity
+                const double zero = 0.0;
+                ICP_HIP_CHECK(hipMemcpyAsync(&w.coarse->tol2, &zero, sizeof(double), hipMemcpyHostToDevice, st));
+                ICP_HIP_CHECK(hipStreamSynchronize(st));
+                hipEvent_t ev[9];
+                for (auto &e : ev) ICP_HIP_CHECK(hipEventCreate(&e));
+                for (double &u : prof->us_kernel) u = 0.0;
+                if (int rc = cg_iterations(4)) return rc;  // warm
+                pev = ev;
+                int rc = cg_iterations(iters);
+                pev = nullptr;
+                if (rc) return rc;
+                for (double &u : prof->us_kernel) u /= iters;
+                int done_it = 0;
+                ICP_HIP_CHECK(hipEventRecord(ev[7], st));
+                while (done_it < iters) {
+                    if (cg.exec && iters - done_it >= kCgChunk) {
+                        ICP_HIP_CHECK(hipEventRecord(ctx->side_ev, st));
+                        ICP_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));
+                        ICP_HIP_CHECK(hipGraphLaunch(cg.exec, ctx->side));
+                        ICP_HIP_CHECK(hipEventRecord(ctx->side_ev, ctx->side));
+                        ICP_HIP_CHECK(hipStreamWaitEvent(st, ctx->side_ev, 0));
+                        done_it += kCgChunk;
+                        prof->graph_replay = 1;
+                    } else {
+                        const int cnt = std::min(kCgChunk, iters - done_it);
+                        if (int rc2 = cg_iterations(cnt)) return rc2;
+                        done_it += cnt;
+                    }
+                }
+                ICP_HIP_CHECK(hipEventRecord(ev[8], st));
+                ICP_HIP_CHECK(hipEventSynchronize(ev[8]));
+                float ms = 0.f;
+                ICP_HIP_CHECK(hipEventElapsedTime(&ms, ev[7], ev[8]));
+                prof->us_iteration = 1e3 * ms / done_it;
+                prof->iterations = done_it;
+                prof->launches_per_iteration = (fused ? 4 : (mixed ? 5 : 6));
+                prof->vertices = d.n;
+                prof->edges = d.e;
+                prof->coarse_columns = nz;
+                for (auto &e : ev) (void)hipEventDestroy(e);
+                w.st = ext;
+                return ICP_OK;
             }
             int cg_done = 0;
             for (int ci = 0; ci < o.max_cg_iters && !cg_done;) {
@@ -3217,6 +3285,23 @@ extern "C" int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const do
     NICP_ARGS(ctx, g);
     ICP_REQUIRE(P_inout && v && nn && c3_host, "null pointer");
     return solve_impl(ctx, g, w, par_single(g, w), P_inout, v, nn, c3_host, flags, opts_in, stats_out);
+}
+
+extern "C" int nicp_profile_cg(icp_ctx *ctx, nicp_graph *g, const double *P, const double *v, const double *nn,
+                               const double *c3_host, unsigned flags, int iterations, nicp_cg_profile *out_host) {
+    NICP_ARGS(ctx, g);
+    ICP_REQUIRE(P && v && nn && c3_host && out_host && iterations > 0, "bad argument");
+    // the solve works on a copy: P is left untouched
+    const Dims d = dims_of(g);
+    double *Pc = nullptr;
+    ICP_HIP_CHECK(hipMalloc((void **)&Pc, d.np * sizeof(double)));
+    int rc = hipMemcpyAsync(Pc, P, d.np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? ICP_OK : ICP_ERR_HIP;
+    std::memset(out_host, 0, sizeof(*out_host));
+    out_host->iterations = iterations;
+    if (!rc) rc = solve_impl(ctx, g, w, par_single(g, w), Pc, v, nn, c3_host, flags, nullptr, nullptr, out_host);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(Pc);
+    return rc;
 }
 
 extern "C" int nicp_solve_dist(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, const double *nn,

@@ -267,6 +267,25 @@ def solve(P, w, source, edges, nn, c, compat=True, opts=None, ctx=None):
                     graph_launches=st.graph_launches)
 
 
+CG_KERNELS = ("fitrow_kernel", "normal_kernel", "cg_sum_alpha_kernel", "cg_update_prec_kernel", "cg_sum_coarse_kernel",
+              "cg_dir_prec_kernel")
+
+
+def profile_cg(P, w, source, edges, nn, c, compat=False, iterations=100, ctx=None):
+    """HIP-event timing of the CG iteration of the first linear solve at P (nicp_profile_cg).  Returns a dict with
+    us_iteration (the solver's own launch path) and us_kernel {name: microseconds}."""
+    ctx = ctx or get_context()
+    v = ctx.to_dev(source)
+    w = _as_weights(w, v.shape[1], ctx)
+    g, ne = w.graph(edges)
+    Pd, nnd = ctx.to_dev(P), ctx.to_dev(nn)
+    pr = _lib.CgProfile()
+    ctx.call("nicp_profile_cg", g, ptr(Pd), ptr(v), ptr(nnd), _c3(c), 1 if compat else 0, int(iterations), ctypes.byref(pr))
+    return dict(iterations=pr.iterations, launches_per_iteration=pr.launches_per_iteration, graph_replay=bool(pr.graph_replay),
+                coarse_columns=pr.coarse_columns, vertices=pr.vertices, edges=pr.edges, us_iteration=pr.us_iteration,
+                us_kernel={k: pr.us_kernel[i] for i, k in enumerate(CG_KERNELS)})
+
+
 def nicp(P, w, source, edges, target, tol, run, c, compat=True, opts=None, history=None, ctx=None):
     """Outer loop of nicp_3d.py:344-363 with the stiffness-halving schedule.
     Returns (deformed, P, (c_fit, c_rigid, c_smooth))."""

@@ -285,6 +285,24 @@ int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, co
                const double *c3_host, unsigned flags, const nicp_solve_opts *opts_host,
                nicp_solve_stats *stats_host);
 
+/* Measurement hook (no counterpart in the reference): sets up the first linear solve of nicp_solve at P exactly as
+ * the solver does (linearisation, column scaling, vertex blocks, coarse matrix) and times its conjugate-gradient
+ * iteration with HIP events on the context's stream: every launch of an iteration separately (plain launches, an
+ * event after each), and the iteration as the solver really runs it (hipGraph replay where enabled).  P is not
+ * modified.  us_kernel = {fitrow_kernel, normal_kernel, cg_sum_alpha_kernel, cg_update_prec_kernel,
+ * cg_sum_coarse_kernel, cg_dir_prec_kernel}; a stage folded into its consumer (small meshes) reads ~0.  Synchronises. */
+typedef struct nicp_cg_profile {
+    int iterations;             /* in: CG iterations to time; out: iterations timed for us_iteration */
+    int launches_per_iteration; /* 4, 5 or 6 */
+    int graph_replay;           /* 1: us_iteration was measured on the hipGraph replay */
+    int coarse_columns;         /* columns of the coarse space in use */
+    int64_t vertices, edges;
+    double us_iteration;        /* microseconds per CG iteration, the solver's own launch path */
+    double us_kernel[6];        /* microseconds between the events around each launch (kernel + launch gap) */
+} nicp_cg_profile;
+int nicp_profile_cg(icp_ctx *ctx, nicp_graph *g, const double *P, const double *v, const double *nn,
+                    const double *c3_host, unsigned flags, int iterations, nicp_cg_profile *out_host);
+
 /* One rank's view of a vertex-sharded solve.  The mesh is cut
  * into vertex ranges; a rank's local mesh is [owned vertices | halo copies] with the fit rows of
  * every vertex whose influence set touches an owned vertex and the edges with an owned endpoint
