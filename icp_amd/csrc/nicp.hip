@@ -1554,8 +1554,21 @@ __device__ __forceinline__ void block_rows_sum_wide(const double *__restrict__ m
     __shared__ double wred[16][kMomSlots];
     const int slot = threadIdx.x & (kMomSlots - 1), grp = threadIdx.x / kMomSlots, ngrp = blockDim.x / kMomSlots;
     double a = 0.0;
-    if (slot < nslots)
-        for (int b = grp; b < nb; b += ngrp) a += mom[(int64_t)b * kMomSlots + slot];
+    if (slot < nslots) {
+        // eight rows in flight per thread (every load issued before the first add; the order of the additions is unchanged)
+        constexpr int BATCH = 8;
+        for (int b0 = grp; b0 < nb; b0 += ngrp * BATCH) {
+            double t[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int b = b0 + u * ngrp;
+                t[u] = b < nb ? mom[(int64_t)b * kMomSlots + slot] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+                if (b0 + u * ngrp < nb) a += t[u];
+        }
+    }
     wred[grp][slot] = a;
     __syncthreads();
     if (threadIdx.x < nslots) {
@@ -1610,34 +1623,84 @@ __global__ __launch_bounds__(1024) void cg_sum_alpha_kernel(const double *__rest
                                                             double *__restrict__ tot, int ng, const double *__restrict__ d2_tail,
                                                             const double *__restrict__ p_tail, double lam,
                                                             double *__restrict__ Ap_tail, Scal *__restrict__ s) {
-    block_rows_sum(partial, nb, mask, tot, 0);
+    // single block on the critical path of every iteration: thread 0 fetches the scalars of the alpha logic BEFORE the
+    // row sums, so their latency overlaps the partial-row loads instead of following them
+    __shared__ double tot_s[kSumSlots];
+    (void)tot;
+    int stop0 = 0;
+    double rz0 = 0.0, dt0[6], pt0[6];
+    if (threadIdx.x == 0) {
+        stop0 = s->stop;
+        rz0 = s->rz;
+        for (int k = 0; k < ng; ++k) {
+            dt0[k] = d2_tail[k];
+            pt0[k] = p_tail[k];
+        }
+    }
+    block_rows_sum(partial, nb, mask, tot_s, 0);
     __syncthreads();
-    if (threadIdx.x == 0) alpha_logic(tot, ng, d2_tail, p_tail, lam, Ap_tail, s);
+    if (threadIdx.x == 0 && !stop0) {  // alpha_logic on the prefetched values (same operations, same order)
+        double pap = tot_s[8];
+        for (int k = 0; k < ng; ++k) {
+            const double val = tot_s[k] + lam * dt0[k] * pt0[k];
+            Ap_tail[k] = val;
+            pap += val * pt0[k];
+        }
+        s->pAp = pap;
+        s->alpha = pap > 0 ? rz0 / pap : 0.0;
+        if (!(pap > 0)) s->stop = 2;  // breakdown (non-positive curvature / NaN)
+    }
 }
 
 // tail update, coarse solve y = Einv Z^T r, r.z, beta, stop test.  tot[0] r.zb, tot[1] r.r, tot[2..2+ng) Z_v^T r
 // tails_done: the (fused) update kernel has already advanced x / r / zb of the tail entries; only read them here
-__device__ __forceinline__ void coarse_logic(const double *tot, int ng, int nm, double *x_tail, double *r_tail, double *zb_tail,
-                                             const double *p_tail, const double *Ap_tail, Coarse *coarse, Scal *s, int init,
-                                             int tails_done = 0) {
+// Everything the coarse logic reads besides the sums, fetched into LDS BEFORE the sums are taken (the kernel is a single
+// block on the critical path of every iteration: its dependent memory round trips are its run time)
+struct CoarsePre {
+    double rt[6], zt[6], pt[6], apt[6], xt[6], minv[6], alpha, rz, tol2, rr0;
+    int stop;
+};
+__device__ __forceinline__ void coarse_prefetch(CoarsePre &pre, int ng, const double *x_tail, const double *r_tail,
+                                                const double *zb_tail, const double *p_tail, const double *Ap_tail,
+                                                const Coarse *coarse, const Scal *s) {
     const int tid = threadIdx.x;
-    const int stop = s->stop;  // uniform: only thread 0 writes it, at the very end
+    if (tid < ng) {
+        pre.rt[tid] = r_tail[tid];
+        pre.zt[tid] = zb_tail[tid];
+        pre.pt[tid] = p_tail[tid];
+        pre.apt[tid] = Ap_tail[tid];
+        pre.xt[tid] = x_tail[tid];
+        pre.minv[tid] = coarse->tail_minv[tid];
+    } else if (tid == 32) {
+        pre.alpha = s->alpha;
+        pre.rz = s->rz;
+        pre.tol2 = coarse->tol2;
+        pre.rr0 = s->rr0;
+        pre.stop = s->stop;
+    }
+}
+// all threads of the block must call it after a __syncthreads() that follows coarse_prefetch; Einv may point to LDS
+__device__ __forceinline__ void coarse_logic(const double *tot, int ng, int nm, double *x_tail, double *r_tail, double *zb_tail,
+                                             Coarse *coarse, Scal *s, int init, int tails_done, const CoarsePre &pre,
+                                             const double *Einv) {
+    const int tid = threadIdx.x;
+    const int stop = pre.stop;  // uniform
     if (stop) return;
     const int nz = nm + ng;  // tot[2..2+nm) Z_v^T r  (nm = ng for the plain coarse space)
     __shared__ double ztr_s[NZMAX], y_s[NZMAX], acc_s[2];
     if (tid == 0) {
         double rz = tot[0], rr = tot[1];
-        const double alpha = s->alpha;
+        const double alpha = pre.alpha;
         for (int k = 0; k < ng; ++k) {
             double rt, zt;
             if (tails_done) {
-                rt = r_tail[k];
-                zt = zb_tail[k];
+                rt = pre.rt[k];
+                zt = pre.zt[k];
             } else {
-                x_tail[k] += alpha * p_tail[k];
-                rt = r_tail[k] - alpha * Ap_tail[k];
+                x_tail[k] = pre.xt[k] + alpha * pre.pt[k];
+                rt = pre.rt[k] - alpha * pre.apt[k];
                 r_tail[k] = rt;
-                zt = rt * coarse->tail_minv[k];
+                zt = rt * pre.minv[k];
                 zb_tail[k] = zt;
             }
             rz += rt * zt;
@@ -1658,7 +1721,7 @@ __device__ __forceinline__ void coarse_logic(const double *tot, int ng, int nm, 
         if (row < nz) {
             double y = 0.0;
             const int b1 = (chunk + 1) * per < nz ? (chunk + 1) * per : nz;
-            for (int b = chunk * per; b < b1; ++b) y += coarse->Einv[b * nz + row] * ztr_s[b];
+            for (int b = chunk * per; b < b1; ++b) y += Einv[b * nz + row] * ztr_s[b];
             ypart[chunk][row] = y;
         }
         __syncthreads();
@@ -1671,7 +1734,7 @@ __device__ __forceinline__ void coarse_logic(const double *tot, int ng, int nm, 
     } else {
         for (int row = tid; row < nz; row += blockDim.x) {  // one row per thread, columns in order
             double y = 0.0;
-            for (int b = 0; b < nz; ++b) y += coarse->Einv[b * nz + row] * ztr_s[b];
+            for (int b = 0; b < nz; ++b) y += Einv[b * nz + row] * ztr_s[b];
             y_s[row] = y;
             coarse->y[row] = y;
         }
@@ -1699,17 +1762,20 @@ __device__ __forceinline__ void coarse_logic(const double *tot, int ng, int nm, 
         s->rr0 = rr;
         s->beta = 0.0;
     } else {
-        s->beta = rz / s->rz;
+        s->beta = rz / pre.rz;
         s->rz = rz;
         s->iters += 1;
-        if (!(rr > coarse->tol2 * s->rr0)) s->stop = 1;
+        if (!(rr > pre.tol2 * pre.rr0)) s->stop = 1;
     }
 }
 __global__ __launch_bounds__(128) void cg_coarse_logic_kernel(const double *__restrict__ tot, int ng, double *__restrict__ x_tail,
                                                             double *__restrict__ r_tail, double *__restrict__ zb_tail,
                                                             const double *__restrict__ p_tail, const double *__restrict__ Ap_tail,
                                                             Coarse *__restrict__ coarse, Scal *__restrict__ s, int init, int nm) {
-    coarse_logic(tot, ng, nm, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s, init);
+    __shared__ CoarsePre pre;
+    coarse_prefetch(pre, ng, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s);
+    __syncthreads();
+    coarse_logic(tot, ng, nm, x_tail, r_tail, zb_tail, coarse, s, init, 0, pre, coarse->Einv);
 }
 // mom != null (enriched coarse space): the moments come from the wide rows, slots 0/1 (r.zb, r.r) from `partial`
 __global__ __launch_bounds__(1024) void cg_sum_coarse_kernel(const double *__restrict__ partial, int nb, unsigned mask,
@@ -1720,11 +1786,17 @@ __global__ __launch_bounds__(1024) void cg_sum_coarse_kernel(const double *__res
                                                              const double *__restrict__ mom, int nm, int tails_done) {
     // the sums stay in LDS (no round trip through `tot`, which nothing else reads on the single-GPU path)
     __shared__ double tot_s[2 + kMomSlots];
+    __shared__ CoarsePre pre;
+    __shared__ double einv_s[NZMAX * NZMAX];
     (void)tot;
+    // E^-1 and the scalars first (coalesced, independent loads): in flight while the partial rows are summed
+    const int nz = nm + ng;
+    for (int i = threadIdx.x; i < nz * nz; i += blockDim.x) einv_s[i] = coarse->Einv[i];
+    coarse_prefetch(pre, ng, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s);
     block_rows_sum(partial, nb, mask, tot_s, 0);
     if (mom) block_rows_sum_wide(mom, nb, nm, tot_s, 2);
     __syncthreads();
-    coarse_logic(tot_s, ng, nm, x_tail, r_tail, zb_tail, p_tail, Ap_tail, coarse, s, init, tails_done);
+    coarse_logic(tot_s, ng, nm, x_tail, r_tail, zb_tail, coarse, s, init, tails_done, pre, einv_s);
 }
 
 // tot[slot] += sum_k a[k] b[k] (w ? w[k] : 1) over the ng replicated tail entries (added on one rank only)
