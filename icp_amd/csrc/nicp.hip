@@ -2027,12 +2027,30 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
     }
 }
 
+// What the fit rows of the NEXT operator application need from this kernel when it also forms them (FIT, see below)
+struct FitArgs {
+    const int32_t *nbr;
+    const double *wt;
+    int K;
+    const double *rs;
+    const Globals *g;
+    double c_fit;
+    double *yfit;
+    double *p_out;  // the new direction goes to a second buffer: neighbours still need the old one
+    RowW rw;
+};
+
 // z = zb + Z y; p = z + beta p
-template <int DIM, bool FUSED>
+// FIT (single GPU): the kernel also writes the fit rows of J p_new (what fitrow_kernel would compute in the next
+// operator application), so that application is normal_kernel alone: one launch and one streamed pass over p less per
+// iteration.  A fit row needs p_new of the vertex's 4 influence neighbours, which other threads of this launch are
+// only just computing -- each thread recomputes them from the neighbours' zb, p_old, P, v by the same operations in
+// the same order (so the rows are bit-identical to fitrow_kernel's), which is why p_new goes to a second buffer.
+template <int DIM, bool FUSED, bool FIT, bool COMPAT>
 __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, const Coarse *__restrict__ coarse,
                                                         const double *__restrict__ P, const double *__restrict__ v, int64_t n,
                                                         const double *__restrict__ zb, double *__restrict__ p, int64_t nown,
-                                                        Strides st, FusedCg f, PolyBasis pb) {
+                                                        Strides st, FusedCg f, PolyBasis pb, FitArgs fa) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
     const int nm = FUSED ? NG : NG * pb.M;  // vertex-mode columns of Z (the fused kernels serve the plain space only)
     __shared__ double y_s[NZMAX];
@@ -2124,14 +2142,14 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, c
         for (int i = threadIdx.x; i < nm + NG; i += blockDim.x) y_s[i] = coarse->y[i];
         __syncthreads();
     }
-    if (j < n) {
-        if (j >= nown) return;  // halo copy
+    // new direction of one vertex from its blocks (in place in pk)
+    auto direction = [&](const double (&Pk)[S], const double (&vk)[DIM], const double (&zbk)[S], double (&pk)[S]) {
         double z[NG][S], yk[NG];
 #pragma unroll
         for (int k = 0; k < NG; ++k) yk[k] = y_s[k];
         if (!FUSED && pb.M > 1) {  // y_k(j) = sum_m y[m*NG + k] phi_m(v_j)
             double phi[MAXPOLY];
-            poly_eval<DIM>(vj_, pb, phi);
+            poly_eval<DIM>(vk, pb, phi);
 #pragma unroll
             for (int m = 1; m < MAXPOLY; ++m) {
                 if (m < pb.M) {  // uniform
@@ -2140,19 +2158,90 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, c
                 }
             }
         }
-        zmodes<DIM>(Pj_, vj_, z);
+        zmodes<DIM>(Pk, vk, z);
 #pragma unroll
         for (int e = 0; e < S; ++e) {
-            double val = zbj[e];
+            double val = zbk[e];
 #pragma unroll
             for (int k = 0; k < NG; ++k) val += yk[k] * z[k][e];
-            pj[e] = val + beta * pj[e];
+            pk[e] = val + beta * pk[e];
         }
+    };
+    double *pw = FIT ? fa.p_out : p;
+    if (j < n) {
+        if (j >= nown) return;  // halo copy (never with FIT: single GPU)
+        if constexpr (FIT) {
+            // the influence neighbours' blocks, all gathers issued before the vertex's own direction is formed
+            constexpr int NANG = Lay<DIM>::NANG;
+            const int K = fa.K;
+            int32_t jj[4];
+            double ww[4], Pn[4][S], vn[4][DIM], zn[4][S], pn[4][S];
 #pragma unroll
-        for (int e = 0; e < S; ++e) p[j * st.pj + e * st.pe] = pj[e];
+            for (int b4 = 0; b4 < 4; ++b4) {
+                const int kk = b4 < K ? b4 : K - 1;
+                jj[b4] = fa.nbr[j * K + kk];
+                ww[b4] = b4 < K ? fa.wt[j * K + kk] : 0.0;
+            }
+#pragma unroll
+            for (int b4 = 0; b4 < 4; ++b4) {
+#pragma unroll
+                for (int e = 0; e < S; ++e) {
+                    const int64_t o = (int64_t)jj[b4] * st.pj + e * st.pe;
+                    Pn[b4][e] = P[o];
+                    zn[b4][e] = zb[o];
+                    pn[b4][e] = p[o];
+                }
+#pragma unroll
+                for (int r = 0; r < DIM; ++r) vn[b4][r] = v[(int64_t)jj[b4] * st.vj + r * st.vc];
+            }
+            double ptail[NG], rsj[DIM];
+#pragma unroll
+            for (int k = 0; k < NG; ++k) ptail[k] = zb[n * S + k] + y_s[nm + k] + beta * p[n * S + k];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) rsj[c] = fa.rs[j * st.vj + c * st.vc];
+            double c_fit = fa.c_fit;
+            if (fa.rw.f2) c_fit *= fa.rw.f2[j];
+            direction(Pj_, vj_, zbj, pj);
+#pragma unroll
+            for (int e = 0; e < S; ++e) pw[j * st.pj + e * st.pe] = pj[e];
+            double acc[DIM];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) acc[c] = 0.0;
+#pragma unroll
+            for (int b4 = 0; b4 < 4; ++b4) {
+                const double wgt = ww[b4];
+                if (wgt == 0.0) continue;
+                direction(Pn[b4], vn[b4], zn[b4], pn[b4]);
+                const double wb = (DIM == 2 && COMPAT) ? 1.0 : wgt;  // Q7
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int r = 0; r < DIM; ++r) a += (vj_[r] - vn[b4][r]) * pn[b4][r * DIM + c];
+                    acc[c] += wgt * a + wb * pn[b4][DIM * DIM + c];
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < DIM; ++o) {
+                double a = ptail[NANG + o];
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) a += acc[c] * fa.g->R[c * DIM + o];
+                for (int an = 0; an < NANG; ++an) {
+                    double b = 0.0;
+#pragma unroll
+                    for (int c = 0; c < DIM; ++c) b += rsj[c] * fa.g->dR[an][c * DIM + o];
+                    a += ptail[an] * b;
+                }
+                fa.yfit[j * st.fj + o * st.fo] = -c_fit * a;
+            }
+        } else {
+            direction(Pj_, vj_, zbj, pj);
+#pragma unroll
+            for (int e = 0; e < S; ++e) pw[j * st.pj + e * st.pe] = pj[e];
+        }
     } else if (j < n + NG) {
         const int k = (int)(j - n);
-        p[n * S + k] = zb[n * S + k] + y_s[nm + k] + beta * p[n * S + k];
+        pw[n * S + k] = zb[n * S + k] + y_s[nm + k] + beta * p[n * S + k];
     }
 }
 
@@ -2270,6 +2359,7 @@ struct Work {
     double *r, *r_trial, *y;               // nr
     double *grad, *col2, *d2, *lamd2;      // np
     double *delta, *rcg, *z, *pcg, *Ap;    // np
+    double *pcg2;                          // np: second direction buffer (the fused direction + fit-row kernel ping-pongs)
     double *x_trial;                       // np
     double *binv;                          // n * S(S+1)/2: inverted diagonal blocks
     Coarse *coarse;
@@ -2287,7 +2377,7 @@ static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     const size_t tri = (size_t)d.S * (d.S + 1) / 2;
     // one row of block partials per block of the per-vertex kernels: sized by the mesh, not by a fixed cap
     const size_t npart = std::max<size_t>(kMaxPartials, (size_t)((d.n + d.NG + g->vb - 1) / g->vb) + 1);
-    const size_t need = small + 2 * npart * kSumSlots + npart * kMomSlots + 4 * (size_t)d.n * d.dim + 4 * (size_t)d.nr + 11 * (size_t)d.np +
+    const size_t need = small + 2 * npart * kSumSlots + npart * kMomSlots + 4 * (size_t)d.n * d.dim + 4 * (size_t)d.nr + 12 * (size_t)d.np +
                         (size_t)d.n * tri + 64;
     if (g->ws_doubles < need) {
         if (g->ws) {
@@ -2316,7 +2406,7 @@ static int get_work(icp_ctx *ctx, nicp_graph *g, Work &w) {
     w.r = p; p += d.nr;
     w.r_trial = p; p += d.nr;
     w.y = p; p += d.nr;
-    double **np_bufs[] = {&w.grad, &w.col2, &w.d2, &w.lamd2, &w.delta, &w.rcg, &w.z, &w.pcg, &w.Ap, &w.x_trial};
+    double **np_bufs[] = {&w.grad, &w.col2, &w.d2, &w.lamd2, &w.delta, &w.rcg, &w.z, &w.pcg, &w.Ap, &w.x_trial, &w.pcg2};
     for (double **b : np_bufs) {
         *b = p;
         p += d.np;
@@ -2504,9 +2594,10 @@ static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const 
 // p . out (slot 8) in w.partial -- what apply_J(sq = 1) followed by apply_JT(finish_tail = false) leaves, without
 // the row vector in between (fitrow_kernel + normal_kernel; ICP_NICP_FUSEDOP=0: the two-kernel pair through w.y)
 static int apply_A(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const double *P, const double *v, const double *c,
-                   bool compat, const double *p, const double *lam_d2, double lam, double *out, hipEvent_t mid = nullptr) {
+                   bool compat, const double *p, const double *lam_d2, double lam, double *out, hipEvent_t mid = nullptr,
+                   bool fit_rows_ready = false) {
     const char *env_op = getenv("ICP_NICP_FUSEDOP");
-    const bool fused_op = !(env_op && atoi(env_op) == 0);
+    const bool fused_op = fit_rows_ready || !(env_op && atoi(env_op) == 0);
     if (!fused_op) {
         if (int rc = apply_J(ctx, g, w, P, v, c, compat, p, w.y, 1)) return rc;
         if (mid) (void)hipEventRecord(mid, ctx->stream);
@@ -2514,9 +2605,10 @@ static int apply_A(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const d
     }
     const int nbk = vgrid(g, g->n);
     const double *rs = compat ? w.dd : w.pre;  // Q6
-    NICP_DISPATCH(g->dim, compat,
-                  hipLaunchKernelGGL((fitrow_kernel<D, C>), dim3(nbk), dim3(g->vb), 0, ctx->stream, p, g->nbr, g->wt, g->k, v, rs, g->n,
-                                     w.glob, c[0], w.y, w.st, w.rw));
+    if (!fit_rows_ready)  // (the fused direction kernel of the previous iteration has written them already)
+        NICP_DISPATCH(g->dim, compat,
+                      hipLaunchKernelGGL((fitrow_kernel<D, C>), dim3(nbk), dim3(g->vb), 0, ctx->stream, p, g->nbr, g->wt, g->k, v, rs, g->n,
+                                         w.glob, c[0], w.y, w.st, w.rw));
     if (mid) (void)hipEventRecord(mid, ctx->stream);  // nicp_profile_cg: boundary between the two kernels
     NICP_DISPATCH(g->dim, compat,
                   hipLaunchKernelGGL((normal_kernel<D, C>), dim3(nbk), dim3(g->vb), 0, ctx->stream, P, p, (const double *)w.y, v, rs,
@@ -3073,7 +3165,10 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             const int nbj = vgrid(g, d.n);  // blocks of the J^T kernel (all local vertices)
             const unsigned ng_mask = (1u << d.NG) - 1u;
             double *x_tail = w.delta + d.n * d.S, *r_tail = w.rcg + d.n * d.S, *zb_tail = w.z + d.n * d.S;
-            double *p_tail = w.pcg + d.n * d.S, *Ap_tail = w.Ap + d.n * d.S;
+            double *Ap_tail = w.Ap + d.n * d.S;
+            // direction buffers: the fused direction + fit-row kernel (dirfit) writes the new direction into the other one
+            double *pbuf[2] = {w.pcg, w.pcg2};
+            int pcur = 0;
             const double *d2_tail = w.d2 + d.n * d.S;
             NICP_DISPATCH(g->dim, compat,
                           hipLaunchKernelGGL((block_diag_kernel<D, C>), dim3((unsigned)((d.n + 63) / 64)), dim3(64), 0, st, (const double *)x,
@@ -3122,6 +3217,13 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             // ---- preconditioned CG on (J^T J + lam D^2) delta = -grad
             ICP_HIP_CHECK(hipMemsetAsync(w.delta, 0, d.np * sizeof(double), st));
             ICP_HIP_CHECK(hipMemsetAsync(w.pcg, 0, d.np * sizeof(double), st));
+            // dirfit (ICP_NICP_DIRFIT=1; single GPU, the reference's 4 influence neighbours): the direction kernel also forms
+            // the next fit rows.  OFF by default -- measured per CG iteration: 10 k vertices 34.0 -> 33.6 us (the launch it
+            // saves costs as much as the four neighbour blocks it recomputes), 200 k vertices 138 -> 166 us (312 B of
+            // gathers per neighbour instead of 120: the direction kernel goes from 17 to 63 us).  Bit-identical either way.
+            bool dirfit = false;
+            if (const char *e = getenv("ICP_NICP_DIRFIT")) dirfit = !par.sharded() && g->k <= 4 && atoi(e) != 0;
+            if (const char *e = getenv("ICP_NICP_FUSEDOP")) dirfit = dirfit && atoi(e) != 0;
             ICP_HIP_CHECK(hipMemsetAsync(w.Ap, 0, d.np * sizeof(double), st));
             hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, -1.0, w.grad, 0.0, (const double *)nullptr, w.rcg, d.np);
             ICP_HIP_CHECK(hipMemsetAsync(w.scal, 0, sizeof(Scal), st));
@@ -3137,12 +3239,15 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             auto precondition = [&](int init, int parity) -> int {
                 const bool fz = fused && !init;            // both stages fused (plain coarse space)
                 const bool fzu = (fused || mixed) && !init;  // the update kernel derives alpha itself
+                double *pk = pbuf[pcur], *p_tail = pk + d.n * d.S;
                 FusedCg fa = {w.partial, nbj, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, fused ? parity : -1};
                 FusedCg fb = {w.partial2, nbv, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, parity};
+                FitArgs fit = {g->nbr, g->wt, g->k, compat ? w.dd : w.pre, w.glob, c[0], w.y, pbuf[pcur ^ 1], w.rw};
                 double *upd_partial = fzu ? w.partial2 : w.partial;
 #define NICP_UPD(D, F) if (rich) { if (prec32) NICP_UPD2(D, F, true, true); else NICP_UPD2(D, F, true, false); } else { if (prec32) NICP_UPD2(D, F, false, true); else NICP_UPD2(D, F, false, false); }
-#define NICP_UPD2(D, F, R, Q) hipLaunchKernelGGL((cg_update_prec_kernel<D, F, R, Q>), dim3(nbv), dim3(g->vb), 0, st, w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)w.pcg, (const double *)w.Ap, (const double *)w.binv, upd_partial, nown, w.st, (const Coarse *)w.coarse, fa, w.mom, w.pb)
-#define NICP_DIR(D, F) hipLaunchKernelGGL((cg_dir_prec_kernel<D, F>), dim3(nbt), dim3(g->vb), 0, st, w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, w.pcg, nown, w.st, fb, w.pb)
+#define NICP_UPD2(D, F, R, Q) hipLaunchKernelGGL((cg_update_prec_kernel<D, F, R, Q>), dim3(nbv), dim3(g->vb), 0, st, w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)pk, (const double *)w.Ap, (const double *)w.binv, upd_partial, nown, w.st, (const Coarse *)w.coarse, fa, w.mom, w.pb)
+#define NICP_DIR2(D, F, T, C) hipLaunchKernelGGL((cg_dir_prec_kernel<D, F, T, C>), dim3(nbt), dim3(g->vb), 0, st, w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, pk, nown, w.st, fb, w.pb, fit)
+#define NICP_DIR(D, F) do { if (dirfit) { if (compat) NICP_DIR2(D, F, true, true); else NICP_DIR2(D, F, true, false); } else NICP_DIR2(D, F, false, false); } while (0)
                 if (g->dim == 3) { if (fzu) { NICP_UPD(3, true); } else { NICP_UPD(3, false); } }
                 else { if (fzu) { NICP_UPD(2, true); } else { NICP_UPD(2, false); } }
                 mark(4);
@@ -3166,7 +3271,9 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
 #undef NICP_UPD
 #undef NICP_UPD2
 #undef NICP_DIR
-                return exchange(ctx, g, w, par, w.pcg);
+#undef NICP_DIR2
+                if (dirfit) pcur ^= 1;  // the new direction (and its fit rows, in w.y) are in the other buffer
+                return exchange(ctx, g, w, par, pbuf[pcur]);
             };
             if (int rc = precondition(1, 0)) return rc;  // alpha = 0: z = M^-1 r, rz, rr0, p = z
             ICP_HIP_CHECK(hipGetLastError());
@@ -3176,8 +3283,9 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             auto cg_iterations = [&](int count) -> int {
                 for (int k = 0; k < count; ++k) {
                     mark(0);
-                    if (int rc = apply_A(ctx, g, w, par, x, v, c, compat, w.pcg, w.lamd2, 1.0, w.Ap, pev ? pev[1] : nullptr)) return rc;
+                    if (int rc = apply_A(ctx, g, w, par, x, v, c, compat, pbuf[pcur], w.lamd2, 1.0, w.Ap, pev ? pev[1] : nullptr, dirfit)) return rc;
                     mark(2);
+                    const double *p_tail = pbuf[pcur] + d.n * d.S;
                     if (fused || mixed) {
                         // the update kernel sums the partials and derives alpha itself
                     } else if (!par.sharded()) {

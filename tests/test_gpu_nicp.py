@@ -339,16 +339,26 @@ def test_fused_operator_is_bit_identical(mods, monkeypatch, case):
     compat = case.endswith("compat")
     opts = dict(max_lm_iters=3, cg_tol=1e-8, max_cg_iters=400)
     out = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("ICP_NICP_FUSEDOP", mode)
+    # (J p rows through memory) | (fused operator, direction and fit rows as two kernels) | (default: the direction
+    # kernel also forms the next fit rows, recomputing the neighbours' new directions)
+    for mode, (fusedop, dirfit) in {"pair": ("0", "0"), "fused": ("1", "0"), "dirfit": ("1", "1")}.items():
+        monkeypatch.setenv("ICP_NICP_FUSEDOP", fusedop)
+        monkeypatch.setenv("ICP_NICP_DIRFIT", dirfit)
         for coarse in ("1", "10" if v.shape[1] == 3 else "6"):
             monkeypatch.setenv("ICP_NICP_COARSE", coarse)
-            P, st = nic.solve(P0, w, v, edges, nn, C, compat=compat, opts=opts)
-            out[mode, coarse] = (P.cpu().numpy(), st)
+            for graph in ("0", "1"):
+                monkeypatch.setenv("ICP_NICP_GRAPH", graph)
+                P, st = nic.solve(P0, w, v, edges, nn, C, compat=compat, opts=opts)
+                st.pop("graph_launches")
+                out[mode, coarse, graph] = (P.cpu().numpy(), st)
     for coarse in ("1", "10" if v.shape[1] == 3 else "6"):
-        a, b = out["0", coarse], out["1", coarse]
-        assert a[1]["cg_iters"] >= 50 and a[1] == b[1]
-        assert np.array_equal(a[0], b[0])
+        a = out["pair", coarse, "0"]
+        assert a[1]["cg_iters"] >= 50
+        for mode in ("pair", "fused", "dirfit"):
+            for graph in ("0", "1"):
+                b = out[mode, coarse, graph]
+                assert a[1] == b[1], (mode, coarse, graph)
+                assert np.array_equal(a[0], b[0]), (mode, coarse, graph)
 
 
 def test_mesh_beyond_the_old_partial_cap(mods):
