@@ -1884,7 +1884,7 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
     double xj[S], rj[S], pj[S], apj[S], zj[S], Pj_[S], vj_[DIM];
     float lrow[P32 ? TRI : 1];
     const bool mine = j < nown;
-    if (mine) {
+    auto load_own = [&]() {
 #pragma unroll
         for (int e = 0; e < S; ++e) {
             const int64_t o = j * st.pj + e * st.pe;
@@ -1901,7 +1901,11 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
 #pragma unroll
             for (int q = 0; q < TRI; ++q) lrow[q] = Lf[(int64_t)q * n];
         }
-    }
+    };
+    // (only where there IS a prologue: on large meshes, whose sums have their own launch, holding ~200 registers
+    // across nothing costs occupancy -- 200 k vertices: 36.7 us with the loads in the body, 48.6 us hoisted)
+    if constexpr (FUSED)
+        if (mine) load_own();
     double alpha_blk = 0.0;
     bool stop_blk;
     if constexpr (FUSED) {
@@ -1959,6 +1963,7 @@ __global__ __launch_bounds__(NB) void cg_update_prec_kernel(Scal *__restrict__ s
     }
     if (mine && !stop_blk) {
         const double alpha = alpha_blk;
+        if constexpr (!FUSED) load_own();
 #pragma unroll
         for (int e = 0; e < S; ++e) {
             xj[e] += alpha * pj[e];
