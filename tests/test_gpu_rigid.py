@@ -314,6 +314,30 @@ def test_match_c4_size_properties(api):
     assert np.array_equal(idx[pick], oi)
 
 
+def test_fused_loop_equals_bruteforce_at_full_size(api):
+    """The path bench.py times -- icp_rigid_run at 2^20 x 2^20 with the grid search, warm-start hints, sorted-position
+    bookkeeping and the XCD 'eighths' block order -- against the same loop on the full scan (ICP_FORCE_BRUTE), 3
+    iterations: identical correspondences; transform and error history to 1e-12 (the two loops add the same numbers in
+    different orders: the brute loop does not Morton-sort its source).  And bench.py's own check: the last
+    correspondences of a K-iteration run equal a brute Match of src . R_{K-1} + t_{K-1}, because the run is
+    bit-reproducible."""
+    torch = api["torch"]
+    rigid = api["rigid"]
+    src, tgt = orc.make_rigid_cloud(1 << 20, seed=1)
+    sd, td = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    a = rigid.rigid_icp(sd, td, 0.0, 3, use_tol=False, want_idx=True)
+    b = rigid.rigid_icp(sd, td, 0.0, 3, use_tol=False, want_idx=True, force_brute=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a["idx"], b["idx"])
+    np.testing.assert_allclose(a["T"].cpu().numpy(), b["T"].cpu().numpy(), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(a["err_hist"].cpu().numpy(), b["err_hist"].cpu().numpy(), rtol=1e-12)
+    a2 = rigid.rigid_icp(sd, td, 0.0, 3, use_tol=False, want_idx=True)          # bit-reproducible
+    assert torch.equal(a["T"], a2["T"]) and torch.equal(a["idx"], a2["idx"]) and torch.equal(a["err_hist"], a2["err_hist"])
+    prev = rigid.rigid_icp(sd, td, 0.0, 2, use_tol=False)["T"]
+    ss = rigid.apply_transform(sd, prev[:3, :3].contiguous(), prev[3, :3].contiguous())
+    assert torch.equal(rigid.closest_indices(ss, td, force_brute=True), a["idx"])
+
+
 # ---------------------------------------------------------------- icp_rigid_run_dist (source-sharded loop below Python)
 @pytest.mark.parametrize("n,m,tol,run,dim", [(60000, 50000, 0.10, 50, 3), (40000, 45000, -np.inf, 7, 3), (3000, 2500, 0.05, 30, 2),
                                              (500, 700, 0.10, 50, 3)])
