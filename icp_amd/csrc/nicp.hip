@@ -19,6 +19,7 @@
 //   Q6 global-rotation Jacobian columns use the already transformed points,
 //   Q7 (2-D) b-columns of the fit block carry no weight factor.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -777,10 +778,13 @@ template <int DIM, bool COMPAT>
 __global__ __launch_bounds__(NB) void fitrow_kernel(const double *__restrict__ p, const int32_t *__restrict__ nbr,
                                                    const double *__restrict__ wt, int K, const double *__restrict__ v,
                                                    const double *__restrict__ rs, int64_t n, const Globals *__restrict__ g,
-                                                   double c_fit, double *__restrict__ yfit, Strides st, RowW rw) {
+                                                   double c_fit, double *__restrict__ yfit, Strides st, RowW rw,
+                                                   const int *__restrict__ stop) {
     constexpr int S = Lay<DIM>::S, NANG = Lay<DIM>::NANG;
     const int64_t t = (int64_t)vblock() * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    // CG iterations are enqueued in chunks (hipGraph replay): those behind the one that converged do nothing
+    if (stop && *stop) return;
     const double *ptail = p + n * S;
     if (rw.f2) c_fit *= rw.f2[t];
     double vi[DIM], acc[DIM];
@@ -843,9 +847,11 @@ __global__ __launch_bounds__(NB) void normal_kernel(const double *__restrict__ P
                                                    const int32_t *__restrict__ inc_other, int64_t n,
                                                    const Globals *__restrict__ g, double c_fit, double c_rigid, double c_smooth,
                                                    const double *__restrict__ lam_d2, double lam, double *__restrict__ out,
-                                                   double *__restrict__ partial, int64_t nown, Strides st, RowW rw) {
+                                                   double *__restrict__ partial, int64_t nown, Strides st, RowW rw,
+                                                   const int *__restrict__ stop) {
     constexpr int S = Lay<DIM>::S, NANG = Lay<DIM>::NANG, NG = Lay<DIM>::NG, NA = Lay<DIM>::NA;
     const int64_t j = (int64_t)vblock() * blockDim.x + threadIdx.x;
+    if (stop && *stop) return;  // (see fitrow_kernel; nobody reads the partial rows of a stopped iteration)
     double gacc[kSumSlots];
 #pragma unroll
     for (int k = 0; k < kSumSlots; ++k) gacc[k] = 0.0;
@@ -1230,7 +1236,14 @@ __device__ __forceinline__ void zmodes(const double *__restrict__ Pj, const doub
     }
 }
 
-// S x S diagonal block of J^T J + lam D^2 for every vertex, inverted; packed lower triangle
+// S x S diagonal block of J^T J + lam D^2 for every vertex, inverted; packed lower triangle.
+// One vertex per lane, everything in registers: only the lower triangle of the block is formed (78 doubles in 3-D,
+// the Cholesky factorisation reads nothing else), the factor and then its inverse overwrite it in place, and every
+// loop over matrix entries has constant bounds, so no index is a run-time value.  (The first form kept three full
+// S x S arrays per lane with run-time indices -- 3.4 KB of scratch memory per lane: 1.15 ms per call at 200 k vertices,
+// one call per LM trial.)  Same operations in the same order per entry: the factor is bit-identical to that form's.
+__host__ __device__ constexpr int tri_index(int a, int b) { return a * (a + 1) / 2 + b; }  // a >= b
+
 template <int DIM, bool COMPAT>
 __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict__ P, const double *__restrict__ wt, int K,
                                                        const double *__restrict__ v, const int32_t *__restrict__ edges,
@@ -1244,22 +1257,26 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
     // prec32 = 1: store the inverse Cholesky factor Li (B^-1 = Li^T Li) in fp32 instead of the packed fp64 inverse:
     // half the bytes of the largest array the CG update kernel streams, and Li^T (Li r) is symmetric positive
     // definite for ANY rounding of Li, which is all a preconditioner has to be
-    constexpr int S = Lay<DIM>::S, NA = Lay<DIM>::NA, NG = Lay<DIM>::NG;
+    constexpr int S = Lay<DIM>::S, NA = Lay<DIM>::NA, NG = Lay<DIM>::NG, TRI = S * (S + 1) / 2;
     const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (j == 0)
         for (int k = 0; k < NG; ++k) coarse->tail_minv[k] = 1.0 / (col2[n * S + k] + lam * d2[n * S + k]);
     if (j >= n) return;
-    double B[S][S];
-    for (int a = 0; a < S; ++a)
-        for (int b = 0; b < S; ++b) B[a][b] = 0.0;
+    double B[TRI];  // lower triangle, row by row
+#pragma unroll
+    for (int q = 0; q < TRI; ++q) B[q] = 0.0;
     double M[DIM][DIM];  // R R^T
+#pragma unroll
     for (int a = 0; a < DIM; ++a)
+#pragma unroll
         for (int b = 0; b < DIM; ++b) {
             double m = 0.0;
+#pragma unroll
             for (int o = 0; o < DIM; ++o) m += g->R[a * DIM + o] * g->R[b * DIM + o];
             M[a][b] = m;
         }
     double vj[DIM];
+#pragma unroll
     for (int a = 0; a < DIM; ++a) vj[a] = v[j * st.vj + a * st.vc];
     // fit rows that reference vertex j: entries -c_fit w d[r] R[c][o] (A) and -c_fit wb R[c][o] (b)
     for (int32_t e = rev_ptr[j]; e < rev_ptr[j + 1]; ++e) {
@@ -1268,34 +1285,41 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
         const double w = wt[ent];
         if (w == 0.0) continue;
         const double wb = (DIM == 2 && COMPAT) ? 1.0 : w;
-        double u[S];  // the row pattern up to the R factor: u[r*DIM+c] = w d[r], u[NA+c] = wb (for column c)
         double d[DIM];
+#pragma unroll
         for (int a = 0; a < DIM; ++a) d[a] = v[i * st.vj + a * st.vc] - vj[a];
         const double cf2 = c_fit * c_fit * (rw.f2 ? rw.f2[i] : 1.0);
+#pragma unroll
         for (int r = 0; r < DIM; ++r)
+#pragma unroll
             for (int c = 0; c < DIM; ++c) {
+#pragma unroll
                 for (int r2 = 0; r2 < DIM; ++r2)
-                    for (int c2 = 0; c2 < DIM; ++c2) B[r * DIM + c][r2 * DIM + c2] += cf2 * w * w * d[r] * d[r2] * M[c][c2];
-                for (int c2 = 0; c2 < DIM; ++c2) {
-                    const double t = cf2 * w * wb * d[r] * M[c][c2];
-                    B[r * DIM + c][NA + c2] += t;
-                    B[NA + c2][r * DIM + c] += t;
-                }
+#pragma unroll
+                    for (int c2 = 0; c2 < DIM; ++c2)
+                        if (r * DIM + c >= r2 * DIM + c2) B[tri_index(r * DIM + c, r2 * DIM + c2)] += cf2 * w * w * d[r] * d[r2] * M[c][c2];
+#pragma unroll
+                for (int c2 = 0; c2 < DIM; ++c2) B[tri_index(NA + c2, r * DIM + c)] += cf2 * w * wb * d[r] * M[c][c2];
             }
+#pragma unroll
         for (int c = 0; c < DIM; ++c)
-            for (int c2 = 0; c2 < DIM; ++c2) B[NA + c][NA + c2] += cf2 * wb * wb * M[c][c2];
-        (void)u;
+#pragma unroll
+            for (int c2 = 0; c2 <= c; ++c2) B[tri_index(NA + c, NA + c2)] += cf2 * wb * wb * M[c][c2];
     }
     // rigid rows: gradients of the NRIG terms w.r.t. the NA entries of A_j
     {
         double A[NA];
+#pragma unroll
         for (int e = 0; e < NA; ++e) A[e] = P[j * st.pj + e * st.pe];
         const double cr2 = c_rigid * c_rigid * (rw.rig ? rw.rig[j] * rw.rig[j] : 1.0);
         constexpr int NRIG = Lay<DIM>::NRIG;
         double G[NRIG][NA];
+#pragma unroll
         for (int m = 0; m < NRIG; ++m)
+#pragma unroll
             for (int e = 0; e < NA; ++e) G[m][e] = 0.0;
         if (DIM == 3) {
+#pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const double a0 = A[c], a1 = A[3 + c], a2 = A[6 + c];
                 G[0][c] = a1; G[0][3 + c] = a0;
@@ -1304,15 +1328,19 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
                 G[3][c] = -2 * a0; G[4][3 + c] = -2 * a1; G[5][6 + c] = -2 * a2;
             }
         } else {
+#pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const double a0 = A[c], a1 = A[2 + c];
                 G[0][c] = a1; G[0][2 + c] = a0;
                 G[1][c] = -2 * a0; G[2][2 + c] = -2 * a1;
             }
         }
+#pragma unroll
         for (int m = 0; m < NRIG; ++m)
+#pragma unroll
             for (int a = 0; a < NA; ++a)
-                for (int b = 0; b < NA; ++b) B[a][b] += cr2 * G[m][a] * G[m][b];
+#pragma unroll
+                for (int b = 0; b <= a; ++b) B[tri_index(a, b)] += cr2 * G[m][a] * G[m][b];
     }
     // smooth rows of the incident edges
     for (int32_t e = inc_ptr[j]; e < inc_ptr[j + 1]; ++e) {
@@ -1322,65 +1350,82 @@ __global__ __launch_bounds__(64) void block_diag_kernel(const double *__restrict
         const int64_t p1 = edges[ed * 2], p2 = edges[ed * 2 + 1];
         const double cs2 = c_smooth * c_smooth * (rw.edge ? rw.edge[ed] * rw.edge[ed] : 1.0);
         double d[DIM];
+#pragma unroll
         for (int a = 0; a < DIM; ++a) d[a] = v[p2 * st.vj + a * st.vc] - v[p1 * st.vj + a * st.vc];
+#pragma unroll
         for (int c = 0; c < DIM; ++c) {
+#pragma unroll
             for (int r = 0; r < DIM; ++r) {
-                for (int r2 = 0; r2 < DIM; ++r2) B[r * DIM + c][r2 * DIM + c] += cs2 * d[r] * d[r2];
-                B[r * DIM + c][NA + c] += sgn * cs2 * d[r];
-                B[NA + c][r * DIM + c] += sgn * cs2 * d[r];
+#pragma unroll
+                for (int r2 = 0; r2 <= r; ++r2) B[tri_index(r * DIM + c, r2 * DIM + c)] += cs2 * d[r] * d[r2];
+                B[tri_index(NA + c, r * DIM + c)] += sgn * cs2 * d[r];
             }
-            B[NA + c][NA + c] += 2 * cs2;
+            B[tri_index(NA + c, NA + c)] += 2 * cs2;
         }
     }
-    for (int a = 0; a < S; ++a) B[a][a] += lam * d2[j * st.pj + a * st.pe];
-    // Cholesky B = L L^T, Linv, Binv = Linv^T Linv; on breakdown fall back to the diagonal
-    double L[S][S];
+    double diag[S];  // for the fall-back below (the factor overwrites B)
+#pragma unroll
+    for (int a = 0; a < S; ++a) {
+        B[tri_index(a, a)] += lam * d2[j * st.pj + a * st.pe];
+        diag[a] = B[tri_index(a, a)];
+    }
+    // Cholesky B = L L^T in place, then L^-1 in place; on breakdown fall back to the diagonal
     bool ok = true;
+#pragma unroll
     for (int a = 0; a < S; ++a)
+#pragma unroll
         for (int b = 0; b <= a; ++b) {
-            double sum = B[a][b];
-            for (int k = 0; k < b; ++k) sum -= L[a][k] * L[b][k];
+            double sum = B[tri_index(a, b)];
+#pragma unroll
+            for (int k = 0; k < b; ++k) sum -= B[tri_index(a, k)] * B[tri_index(b, k)];
             if (a == b) {
                 if (!(sum > 0.0)) ok = false;
-                L[a][a] = ok ? sqrt(sum) : 1.0;
+                B[tri_index(a, a)] = ok ? sqrt(sum) : 1.0;
             } else {
-                L[a][b] = sum / L[b][b];
+                B[tri_index(a, b)] = sum / B[tri_index(b, b)];
             }
         }
     // packed lower triangle, entry q of vertex j at binv[q*n + j] (coalesced for the per-vertex lanes)
     double *out = binv + j;
     float *out32 = (float *)binv + j;
     if (!ok) {
-        int q = 0;
+#pragma unroll
         for (int a = 0; a < S; ++a)
+#pragma unroll
             for (int b = 0; b <= a; ++b) {
-                if (prec32) out32[(int64_t)(q++) * n] = a == b ? (float)(1.0 / sqrt(B[a][a])) : 0.0f;
-                else out[(int64_t)(q++) * n] = a == b ? 1.0 / B[a][a] : 0.0;
+                if (prec32) out32[(int64_t)tri_index(a, b) * n] = a == b ? (float)(1.0 / sqrt(diag[a])) : 0.0f;
+                else out[(int64_t)tri_index(a, b) * n] = a == b ? 1.0 / diag[a] : 0.0;
             }
         return;
     }
-    double Li[S][S];  // inverse of L (lower)
-    for (int a = 0; a < S; ++a)
-        for (int b = 0; b < S; ++b) Li[a][b] = 0.0;
+    // column c of Li = L^-1 needs the columns >= c of L and the diagonal entries below: ascending c leaves them intact
+#pragma unroll
     for (int c = 0; c < S; ++c) {
-        Li[c][c] = 1.0 / L[c][c];
+        double col[S];  // L[:, c] (the sums read it while Li[:, c] is being written)
+#pragma unroll
+        for (int a = c + 1; a < S; ++a) col[a] = B[tri_index(a, c)];
+        B[tri_index(c, c)] = 1.0 / B[tri_index(c, c)];
+#pragma unroll
         for (int a = c + 1; a < S; ++a) {
             double sum = 0.0;
-            for (int k = c; k < a; ++k) sum -= L[a][k] * Li[k][c];
-            Li[a][c] = sum / L[a][a];
+#pragma unroll
+            for (int k = c; k < a; ++k) sum -= (k == c ? col[a] : B[tri_index(a, k)]) * B[tri_index(k, c)];
+            B[tri_index(a, c)] = sum / B[tri_index(a, a)];
         }
     }
-    int q = 0;
     if (prec32) {
-        for (int a = 0; a < S; ++a)
-            for (int b = 0; b <= a; ++b) out32[(int64_t)(q++) * n] = (float)Li[a][b];
+#pragma unroll
+        for (int q = 0; q < TRI; ++q) out32[(int64_t)q * n] = (float)B[q];
         return;
     }
+#pragma unroll
     for (int a = 0; a < S; ++a)
+#pragma unroll
         for (int b = 0; b <= a; ++b) {
             double sum = 0.0;
-            for (int k = a; k < S; ++k) sum += Li[k][a] * Li[k][b];
-            out[(int64_t)(q++) * n] = sum;
+#pragma unroll
+            for (int k = a; k < S; ++k) sum += B[tri_index(k, a)] * B[tri_index(k, b)];
+            out[(int64_t)tri_index(a, b) * n] = sum;
         }
 }
 
@@ -2600,7 +2645,7 @@ static int apply_JT(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const 
 // the row vector in between (fitrow_kernel + normal_kernel; ICP_NICP_FUSEDOP=0: the two-kernel pair through w.y)
 static int apply_A(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const double *P, const double *v, const double *c,
                    bool compat, const double *p, const double *lam_d2, double lam, double *out, hipEvent_t mid = nullptr,
-                   bool fit_rows_ready = false) {
+                   bool fit_rows_ready = false, const int *stop = nullptr) {
     const char *env_op = getenv("ICP_NICP_FUSEDOP");
     const bool fused_op = fit_rows_ready || !(env_op && atoi(env_op) == 0);
     if (!fused_op) {
@@ -2613,12 +2658,12 @@ static int apply_A(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par, const d
     if (!fit_rows_ready)  // (the fused direction kernel of the previous iteration has written them already)
         NICP_DISPATCH(g->dim, compat,
                       hipLaunchKernelGGL((fitrow_kernel<D, C>), dim3(nbk), dim3(g->vb), 0, ctx->stream, p, g->nbr, g->wt, g->k, v, rs, g->n,
-                                         w.glob, c[0], w.y, w.st, w.rw));
+                                         w.glob, c[0], w.y, w.st, w.rw, stop));
     if (mid) (void)hipEventRecord(mid, ctx->stream);  // nicp_profile_cg: boundary between the two kernels
     NICP_DISPATCH(g->dim, compat,
                   hipLaunchKernelGGL((normal_kernel<D, C>), dim3(nbk), dim3(g->vb), 0, ctx->stream, P, p, (const double *)w.y, v, rs,
                                      g->rev_ptr, g->rev_i, g->rev_w, g->inc_ptr, g->inc_ent, g->inc_other, g->n, w.glob, c[0], c[1],
-                                     c[2], lam_d2, lam, out, w.partial, par.nown, w.st, w.rw));
+                                     c[2], lam_d2, lam, out, w.partial, par.nown, w.st, w.rw, stop));
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
 }
@@ -3054,6 +3099,21 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
     int e_lag = 8, e_age = -1, e_M = 0;  // coarse-matrix reuse: rebuilt every 8th linear solve (ICP_NICP_ELAG overrides)
     if (const char *e = getenv("ICP_NICP_ELAG")) e_lag = std::max(1, atoi(e));
     const bool trace = getenv("ICP_NICP_TRACE") != nullptr && par_in.rank() == 0;  // one line per LM trial on stderr
+    // ICP_NICP_TIMING: host wall time of the sections of a solve (synchronising after each: development only)
+    const bool timing = getenv("ICP_NICP_TIMING") != nullptr && par_in.rank() == 0;
+    double tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto tnow = [&]() -> double {
+        if (!timing) return 0.0;
+        (void)hipStreamSynchronize(ctx->stream);
+        return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    double tlast = tnow();
+    auto tick = [&](int k) {
+        if (!timing) return;
+        const double t = tnow();
+        tsec[k] += t - tlast;
+        tlast = t;
+    };
 
     // ---- solver-internal, lane-transposed copies of the inputs (see Strides)
     if (int rc = refuse_compat_weights(w, compat)) return rc;
@@ -3113,6 +3173,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
     double f2 = ht[0];
     stt.err0 = f2;
     stt.nfev = 1;
+    tick(0);  // set-up: layouts, mesh statistics, first residual
     double lam = o.lambda0, nu = 2.0;
     int info = 0;
     bool first_scaling = true;
@@ -3156,6 +3217,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
         if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, r_for_grad, nullptr, nullptr, 0.0, w.grad, false)) return rc;
         if (int rc = apply_JT(ctx, g, w, par, x, v, c, compat, w.r, nullptr, nullptr, 0.0, w.col2, true)) return rc;
         const double cg_tol_now = o.cg_tol;
+        tick(1);  // linearisation + gradient
         bool accepted = false;
         bool relinearise = false;
         while (!accepted && !info && stt.nfev < maxfev) {
@@ -3202,6 +3264,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 hipLaunchKernelGGL(ecol_logic_kernel, dim3(1), dim3(128), 0, st, (const double *)par.tot, d.NG, nm, d2_tail, lam, a, w.coarse);
             }
             ICP_HIP_CHECK(hipGetLastError());
+            tick(1);
             if (rebuild_E) {
                 double E[NZMAX * NZMAX], Einv[NZMAX * NZMAX];
                 ICP_HIP_CHECK(hipMemcpyAsync(E, w.coarse->E, sizeof(double) * nz * nz, hipMemcpyDeviceToHost, st));
@@ -3219,6 +3282,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 ICP_HIP_CHECK(hipMemcpyAsync(&w.coarse->tol2, &tol2, sizeof(double), hipMemcpyHostToDevice, st));
                 ICP_HIP_CHECK(hipStreamSynchronize(st));  // both sources are on this stack frame
             }
+            tick(2);  // vertex blocks + coarse matrix
             // ---- preconditioned CG on (J^T J + lam D^2) delta = -grad
             ICP_HIP_CHECK(hipMemsetAsync(w.delta, 0, d.np * sizeof(double), st));
             ICP_HIP_CHECK(hipMemsetAsync(w.pcg, 0, d.np * sizeof(double), st));
@@ -3288,7 +3352,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             auto cg_iterations = [&](int count) -> int {
                 for (int k = 0; k < count; ++k) {
                     mark(0);
-                    if (int rc = apply_A(ctx, g, w, par, x, v, c, compat, pbuf[pcur], w.lamd2, 1.0, w.Ap, pev ? pev[1] : nullptr, dirfit)) return rc;
+                    if (int rc = apply_A(ctx, g, w, par, x, v, c, compat, pbuf[pcur], w.lamd2, 1.0, w.Ap, pev ? pev[1] : nullptr, dirfit, &w.scal->stop)) return rc;
                     mark(2);
                     const double *p_tail = pbuf[pcur] + d.n * d.S;
                     if (fused || mixed) {
@@ -3342,6 +3406,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                     cg.failed = true;
                 }
             }
+            tick(3);  // CG start + graph capture / instantiation
             if (prof) {
                 // Measurement only (nicp_profile_cg): the stop tolerance is zeroed so that no kernel takes its early
                 // exit, then (1) `iterations` CG iterations as plain launches with an event after every launch and
@@ -3408,6 +3473,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 cg_done = hs.stop;
             }
             stt.cg_iters += hs.iters;
+            tick(4);  // CG iterations
             if (hs.iters > 400 && w.pb.M < coarse_switch_to) w.pb.M = coarse_switch_to;  // same decision on every rank (global counters)
             if (int rc = exchange(ctx, g, w, par, w.delta)) return rc;
             // ---- trial point and gain ratio
@@ -3422,6 +3488,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             if (int rc = allreduce(par, 5)) return rc;
             if (int rc = read_tot(ctx, par, 5, ht)) return rc;
             stt.nfev++;
+            tick(5);  // trial point
             const double f2t = ht[0], dn2 = ht[1], dg = ht[2], xn2 = ht[3], gg = ht[4];
             const double pred = lam * dn2 - dg;  // = |r|^2 - |r + J delta|^2 - lam|D delta|^2 ... >= 0 for an exact solve
             const double actred = f2 - f2t;
@@ -3461,6 +3528,10 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
     if (int rc = relayout(ctx, x, soa.pj, soa.pe, P_inout, ext.pj, ext.pe, d.n, d.S)) return rc;
     ICP_HIP_CHECK(hipMemcpyAsync(P_inout + d.n * d.S, x + d.n * d.S, d.NG * sizeof(double), hipMemcpyDeviceToDevice, st));
     ICP_HIP_CHECK(hipStreamSynchronize(st));
+    tick(6);
+    if (timing)
+        std::fprintf(stderr, "nicp_solve timing [ms]: setup %.2f  linearise+grad+blocks %.2f  coarse matrix %.2f  cg start+graph %.2f  cg %.2f  trial %.2f  finish %.2f  (lm %d, cg %d)\n",
+                     1e3 * tsec[0], 1e3 * tsec[1], 1e3 * tsec[2], 1e3 * tsec[3], 1e3 * tsec[4], 1e3 * tsec[5], 1e3 * tsec[6], stt.lm_iters, stt.cg_iters);
     return ICP_OK;
 }
 
