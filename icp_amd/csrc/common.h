@@ -94,7 +94,7 @@ struct GridBuild {
 int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, int slot = 0);
 // same, into caller-owned scratch (persistent target handles)
 int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, Scratch &sa, Scratch &sb,
-                    Scratch &sc, Scratch &sd);
+                    Scratch &sc, Scratch &sd, bool stable = false);
 int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
                const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done, const int32_t *hint = nullptr,
                bool pos_mode = false);
