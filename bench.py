@@ -95,6 +95,22 @@ def cpu_baseline(src, tgt, sample, numpy_queries):
                               % (numpy_queries, tgt.shape[0], dq * 1e3, dq * src.shape[0] / 3600.0),
             "c1_icp_iters_per_s": 30.0 / d1,
             "c1_sample": "config C1 in full: ICP(1000 x 1000 points, 30 forced iterations) with the numpy restatement, %.2f s" % d1}
+    if numpy_queries > 0:
+        # (iii) of SURVEY.md 8d: the reference's NICP formulation (dense D_MinFunc + scipy leastsq = MINPACK lmder) is
+        # only runnable on tiny meshes (the dense J of C3 would be 260 GB): 60 vertices, 3 outer iterations
+        v, edges, t60 = orc.make_grid_mesh(10, 6, seed=3)
+        nbr, wt = orc.knn_weights(v)
+        P0 = orc.initialise(v)[0]
+        hist = []
+        t0 = time.perf_counter()
+        orc.nicp(P0, nbr, wt, v, edges, t60, 0.01, 3, history=hist)
+        d60 = time.perf_counter() - t0
+        out["nicp_reference_formulation"] = {
+            "kind": "port", "cores": 1, "vertices": int(v.shape[0]), "edges": int(len(edges)), "outer_iters": len(hist),
+            "seconds": d60, "outer_iters_per_s": len(hist) / d60,
+            "sample": "nicp_3d.py:344-363 restated (dense Jacobian of 9N+6E x 12N+6 entries + scipy.optimize.leastsq) on a "
+                      "%d-vertex mesh, %d outer iterations, %.1f s; C3 in this formulation needs a 260 GB Jacobian" %
+                      (v.shape[0], len(hist), d60)}
     return out
 
 
