@@ -60,8 +60,20 @@ namespace icp {
 
 constexpr int NB = 256;
 constexpr int KNN_TILE = 512;
-constexpr int kCgChunk = 50;  // CG iterations between two host reads of the stop flag (= one hipGraph replay)
-static_assert(kCgChunk % 2 == 0, "the fused CG kernels alternate a parity that must restart at 0 with every chunk");
+// CG iterations between two host reads of the stop flag (= one hipGraph replay).  Even: the fused CG kernels alternate
+// a parity that must restart at 0 with every chunk.  20: in the reference's mode most LM trials are rejected and their
+// CG solves take 30-100 iterations, so what is enqueued behind the converged iteration is mostly waste even though
+// those kernels return at once (C3 reference mode: chunks of 10 / 20 / 30 / 50 / 100 -> 0.40 / 0.385 / 0.40 / 0.43 /
+// 0.52 s; the long solves of the self-consistent mode do not care: 15.83 vs 15.84 s).  ICP_NICP_CHUNK overrides.
+static int cg_chunk_size() {
+    static const int v = [] {
+        const char *e = getenv("ICP_NICP_CHUNK");
+        const int c = e ? atoi(e) : 20;
+        return c >= 2 ? (c & ~1) : 20;
+    }();
+    return v;
+}
+#define kCgChunk (cg_chunk_size())
 
 template <int DIM>
 struct Lay {

@@ -269,7 +269,7 @@ typedef struct nicp_solve_stats {
     double err0; /* ... at the initial P */
     int lm_iters, cg_iters, nfev;
     int info;    /* 1 ftol, 2 xtol, 3 both, 4 gtol, 5 iteration / evaluation limit */
-    int graph_launches; /* 50-iteration CG chunks replayed as one hipGraph (0: plain launches; see ICP_NICP_GRAPH) */
+    int graph_launches; /* 20-iteration CG chunks replayed as one hipGraph (0: plain launches; see ICP_NICP_GRAPH) */
 } nicp_solve_stats;
 
 /* The optimize.leastsq call of nicp_3d.py:351 / nicp_row.py:246: minimise |MinFunc(P)|^2 from
@@ -278,7 +278,7 @@ typedef struct nicp_solve_stats {
  * preconditioned by the inverted per-vertex blocks plus a coarse space of the modes the stiffness
  * terms cannot see: 12 columns (6 in 2-D), enriched to 66 (21) -- those modes times the quadratic
  * polynomials of the vertex position -- on meshes of >= 2048 vertices once a linear solve needs more
- * than 400 iterations (environment ICP_NICP_COARSE = 1 | 4 | 10 fixes the space).  On one GPU the CG iterations are replayed 50 at a time
+ * than 400 iterations (environment ICP_NICP_COARSE = 1 | 4 | 10 fixes the space).  On one GPU the CG iterations are replayed 20 at a time
  * as a hipGraph captured once per solve (meshes of >= 1024 vertices; environment ICP_NICP_GRAPH=0/1
  * forces it off/on; same kernels, same bits).  opts_host may be NULL; stats_host may be NULL.  Synchronises. */
 int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const double *v, const double *nn,
