@@ -5,8 +5,9 @@
 // the Kabsch sums of icp_rigid_run run over the Morton-sorted source, and a different order of the same summands moved
 // the transform in its last bits.  A stable LSD radix sort of the codes, with the point indices 0..m-1 as payload,
 // leaves every cell in ascending index order: the ordering, hence every sum over it, is reproducible.
-// The sort itself is rocPRIM's (a plain library operation, once per point set); only the significant code bits
-// are sorted (3 passes at 2^20 points).
+// The sort itself is rocPRIM's (a plain library operation, once per sorted SOURCE; grids that are only searched fill
+// their cells without it, grid.hip scatter_atomic_kernel); only the significant code bits are compared.  At 2^20 pairs
+// rocPRIM takes its block-sort + merge path: about 20 small kernels, 160 us (profiles/r2_kernel_stats_grid.txt).
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
