@@ -54,3 +54,16 @@ def test_error_reporting_without_gpu():
     lib = _lib.load_library()
     assert lib.icp_closest(None, None, 1, None, 1, 3, 0, None, None) == -1      # ICP_ERR_ARG, no launch
     assert b"null pointer" in lib.icp_last_error()
+
+
+def test_header_is_plain_c_and_the_c_example_compiles(tmp_path):
+    """include/icp_hip.h is a C header (the drop-in boundary is a C-ABI): strict C99, no warnings; the plain-C host of
+    examples/ compiles against it (linking needs the library, which the GPU test of that program covers)."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "icp_hip.h")
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include "icp_hip.h"\nint main(void) { return (int)sizeof(icp_comm) + (int)sizeof(nicp_cg_profile) > 0 ? 0 : 1; }\n')
+    for src in (str(probe), os.path.join(ROOT, "examples", "rigid_c_abi.c")):
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.dirname(hdr), "-c", src,
+                            "-o", str(tmp_path / "o.o")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr

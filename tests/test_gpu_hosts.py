@@ -272,3 +272,42 @@ def test_bench_contract_line():
     e = d["extra"]
     assert len(e["timed_calls_ms_per_step"]) == 3 and e["repeats"]["min_ms_per_step"] <= d["ms_per_step"] <= e["repeats"]["max_ms_per_step"]
     assert e["setup_ms"] is not None
+
+
+@pytest.mark.gpu
+def test_plain_c_host_of_the_c_abi():
+    """examples/rigid_c_abi.c (C99, no HIP headers, icp_malloc / icp_memcpy only) runs ICP through icp_rigid_run and gets
+    the numbers the Python host gets on the same doubles; icp_find_transform_noalloc == icp_find_transform there too;
+    a bad argument comes back as a return code."""
+    exe = os.path.join(ROOT, "icp_amd", "rigid_c_abi")
+    assert os.path.exists(exe), "build icp_amd/rigid_c_abi first (make -C icp_amd/csrc)"
+    n, run = 6000, 40
+    r = subprocess.run([exe, str(n), str(run)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = {}
+    for ln in r.stdout.splitlines():
+        k, *v = ln.split()
+        out.setdefault(k, []).append(v)
+    # the program's clouds, rebuilt from its LCG
+    state, vals = 12345, np.empty(n * 3)
+    for i in range(n * 3):
+        state = (state * 1664525 + 1013904223) & 0xFFFFFFFF
+        vals[i] = state / 4294967296.0
+    tgt = vals.reshape(n, 3)
+    c, s = np.cos(0.05), np.sin(0.05)
+    p = tgt[::-1] - np.array([0.01, 0.005, -0.002])
+    src = np.stack([c * p[:, 0] - s * p[:, 1], s * p[:, 0] + c * p[:, 1], p[:, 2]], 1)
+    from icp_amd import rigid
+    ref = rigid.rigid_icp(src, tgt, 1e-9, run, want_idx=True)
+    k = int(ref["iters"].cpu()[0])
+    assert int(out["iters"][0][0]) == k
+    T = np.array([[float(x) for x in row] for row in out["T"]])
+    np.testing.assert_allclose(T, ref["T"].cpu().numpy(), rtol=0, atol=1e-13)
+    hist = np.array([float(v[1]) for v in out["err"]])
+    np.testing.assert_allclose(hist, ref["err_hist"].cpu().numpy()[:k], rtol=1e-12)
+    assert out["find_transform_noalloc_identical"][0][0] == "1"
+    recovered = int((ref["idx"].cpu().numpy() == np.arange(n)[::-1]).sum())
+    assert out["correspondences_recovered"][0] == [str(recovered), "of", str(n)]
+    assert int(out["bad_dim_rc"][0][0]) == -1                       # ICP_ERR_ARG
+    R = np.array([[float(x) for x in row] for row in out["R"]])
+    np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-12)
