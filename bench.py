@@ -308,8 +308,8 @@ def main():
                         "path (TA busy 66-82%%) and fp64 VALU (~50%%) on gathers from the L2/MALL-resident sorted target, "
                         "not by HBM, so the HBM fraction is low by construction; equivalent brute-force rate = %.3g "
                         "pair-evaluations/s" % (gbytes / 1e6, pairs / t_kernel)}
-        try:   # HBM-side bytes per launch from the committed PMC passes (profiles/r1_pmc_grid.txt); valid for the default size only
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+        try:   # HBM-side bytes per launch from the committed PMC passes (profiles/r2_pmc_grid.txt); valid for the default size only
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
             if n == (1 << 20) and world == 1:
                 roof["traffic"] = tr["traffic_bytes"]
                 roof["traffic_source"] = tr["source"]
