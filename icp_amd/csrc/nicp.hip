@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(NB) void normal_kernel(const double *__restrict__ P
 // ------------------------------------------------------------------ vector kernels
 // device scalars used by the CG / LM loops
 struct Scal {
-    double rz, rz_new, pAp, rr, rr0, alpha, beta, tmp[8];
+    double rz, rz_new, pAp, rr, rr0, alpha, beta, tmp[8], rz0;
     int32_t stop, iters;
 };
 
@@ -1211,7 +1211,8 @@ struct Coarse {
     double E[NZMAX * NZMAX];
     double ztr[NZMAX], y[NZMAX];
     double tail_minv[6];
-    double tol2;  // square of the relative residual at which this CG solve stops (device-resident: may change per LM step)
+    double tol2;   // square of the relative residual at which this CG solve stops (device-resident: may change per LM step)
+    double tol2z;  // the same bound on the PRECONDITIONED residual r.z / r0.z0 (+inf: not tested); directly behind tol2
 };
 
 // the NG per-vertex zero-stiffness modes at vertex j: z[k][0..S)
@@ -1714,7 +1715,7 @@ __global__ __launch_bounds__(1024) void cg_sum_alpha_kernel(const double *__rest
 // Everything the coarse logic reads besides the sums, fetched into LDS BEFORE the sums are taken (the kernel is a single
 // block on the critical path of every iteration: its dependent memory round trips are its run time)
 struct CoarsePre {
-    double rt[6], zt[6], pt[6], apt[6], xt[6], minv[6], alpha, rz, tol2, rr0;
+    double rt[6], zt[6], pt[6], apt[6], xt[6], minv[6], alpha, rz, tol2, rr0, tol2z, rz0;
     int stop;
 };
 __device__ __forceinline__ void coarse_prefetch(CoarsePre &pre, int ng, const double *x_tail, const double *r_tail,
@@ -1733,6 +1734,8 @@ __device__ __forceinline__ void coarse_prefetch(CoarsePre &pre, int ng, const do
         pre.rz = s->rz;
         pre.tol2 = coarse->tol2;
         pre.rr0 = s->rr0;
+        pre.tol2z = coarse->tol2z;
+        pre.rz0 = s->rz0;
         pre.stop = s->stop;
     }
 }
@@ -1817,12 +1820,13 @@ __device__ __forceinline__ void coarse_logic(const double *tot, int ng, int nm, 
         s->rz = rz;
         s->tmp[0] = rz;  // the fused kernels keep r.z in tmp[parity of the iteration] (see FusedCg)
         s->rr0 = rr;
+        s->rz0 = rz;
         s->beta = 0.0;
     } else {
         s->beta = rz / pre.rz;
         s->rz = rz;
         s->iters += 1;
-        if (!(rr > pre.tol2 * pre.rr0)) s->stop = 1;
+        if (!(rr > pre.tol2 * pre.rr0) && !(rz > pre.tol2z * pre.rz0)) s->stop = 1;
     }
 }
 __global__ __launch_bounds__(128) void cg_coarse_logic_kernel(const double *__restrict__ tot, int ng, double *__restrict__ x_tail,
@@ -2139,12 +2143,14 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, c
         __shared__ int stop_sh;
         // scalars and the rows of E^-1, fetched before the sums they meet
         int stop0 = 0;
-        double rt0[NG], zt0[NG], rzold0 = 0.0, tol20 = 0.0, rr00 = 0.0, erow[2 * NG];
+        double rt0[NG], zt0[NG], rzold0 = 0.0, tol20 = 0.0, rr00 = 0.0, tol2z0 = 0.0, rz00 = 0.0, erow[2 * NG];
         if (threadIdx.x == 0) {
             stop0 = s->stop;
             rzold0 = s->tmp[f.parity];
             tol20 = coarse->tol2;
             rr00 = s->rr0;
+            tol2z0 = coarse->tol2z;
+            rz00 = s->rz0;
             for (int k = 0; k < NG; ++k) {
                 rt0[k] = f.r_tail[k];
                 zt0[k] = f.zb_tail[k];
@@ -2182,7 +2188,7 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, c
             const double rr = acc_s[1];
             for (int a = 0; a < nz; ++a) rz += ztr_s[a] * y_s[a];
             const double bt = rz / rzold0;
-            const bool done = !(rr > tol20 * rr00);
+            const bool done = !(rr > tol20 * rr00) && !(rz > tol2z0 * rz00);
             if (blockIdx.x == 0) {
                 s->rz_new = rz;
                 s->rr = rr;
@@ -3290,8 +3296,18 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 ICP_HIP_CHECK(hipStreamSynchronize(st));  // the source is on this stack frame
             }
             {
-                const double tol2 = cg_tol_now * cg_tol_now;
-                ICP_HIP_CHECK(hipMemcpyAsync(&w.coarse->tol2, &tol2, sizeof(double), hipMemcpyHostToDevice, st));
+                // [tol2, tol2z].  The stop test is on the residual |r| / |g|.  With the reference's constants (c_rigid 1000
+                // against c_fit 0.1) the system is badly scaled, and a small |r| then says little about the soft (fit)
+                // components of the step: tests/fuzz_nicp.py found LM steps 2e-6 away from the dense solve at cg_tol
+                // 1e-13.  A caller who asks for a tight solve (cg_tol < 1e-6) therefore also gets the PRECONDITIONED
+                // residual r.z / r0.z0 held to the same bound (the step then matches the refined dense solve to 1e-9 in all
+                // 420 fuzz cases).  The default tolerance (1e-4) keeps the plain test: the LM loop corrects an inexact step
+                // with the next one, and the stricter test costs 24-39 % more CG iterations for the same LM history (C3
+                // reference mode 9 232 -> 11 441, self-consistent 423 k -> 587 k).  ICP_NICP_STOP = 0 / 1 forces either.
+                static const int stop_mode = getenv("ICP_NICP_STOP") ? atoi(getenv("ICP_NICP_STOP")) : -1;
+                const bool both = stop_mode < 0 ? cg_tol_now < 1e-6 : stop_mode != 0;
+                const double tol2[2] = {cg_tol_now * cg_tol_now, both ? cg_tol_now * cg_tol_now : HUGE_VAL};
+                ICP_HIP_CHECK(hipMemcpyAsync(&w.coarse->tol2, tol2, sizeof(tol2), hipMemcpyHostToDevice, st));
                 ICP_HIP_CHECK(hipStreamSynchronize(st));  // both sources are on this stack frame
             }
             tick(2);  // vertex blocks + coarse matrix

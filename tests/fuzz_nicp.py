@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the NICP operators on the GPU against the CPU oracle (test infrastructure, hence under
+tests/; not collected by pytest -- run by name on a GPU box):  python tests/fuzz_nicp.py [--cases 200] [--seed 0]
+Random small meshes (3-D and 2-D), random parameter vectors, random stiffness constants, both modes: KNN weights,
+Deform, residual, J v, J^T u and one Levenberg-Marquardt step against the dense solve, each to 1e-6 relative."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+import icp_oracle as orc  # noqa: E402
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    import torch
+    from icp_amd import nicp
+    rng = np.random.default_rng(args.seed)
+    bad = 0
+    for case in range(args.cases):
+        dim = int(rng.choice([2, 3]))
+        n = int(rng.integers(8, 140))
+        compat = bool(rng.integers(0, 2))
+        # a bumpy sheet (3-D) / a wiggly band (2-D): distinct points, no exact KNN ties
+        if dim == 3:
+            uv = rng.uniform(-1, 1, (n, 2))
+            v = np.stack([uv[:, 0], uv[:, 1], 0.3 * np.sin(2 * uv[:, 0]) * np.cos(uv[:, 1])], 1)
+        else:
+            t = np.sort(rng.uniform(-2, 2, n))
+            v = np.stack([t, 0.4 * np.sin(2 * t) + 0.05 * rng.standard_normal(n)], 1)
+        v = v * float(rng.choice([0.1, 1.0, 7.0]))
+        # edges: every vertex to its 2-3 nearest others, deduplicated
+        d = ((v[:, None, :] - v[None, :, :]) ** 2).sum(-1)
+        np.fill_diagonal(d, np.inf)
+        nb = np.argsort(d, 1)[:, : int(rng.integers(2, 4))]
+        edges = np.unique(np.sort(np.stack([np.repeat(np.arange(n), nb.shape[1]), nb.ravel()], 1), 1), axis=0).astype(np.int32)
+        S = dim * dim + dim
+        ng = 3 if dim == 2 else 6
+        P = np.append(np.tile(np.append(np.eye(dim).ravel(), np.zeros(dim)), n), np.zeros(ng))
+        P = P + rng.standard_normal(P.shape) * float(rng.choice([0.0, 0.01, 0.2]))
+        nn = v + rng.standard_normal(v.shape) * 0.05 * np.abs(v).max()
+        c = (float(rng.choice([0.1, 1.0])), float(rng.choice([1000.0, 30.0, 1.0])), float(rng.choice([100.0, 3.0, 0.1])))
+        nbr, wt = orc.knn_weights(v)
+        w = nicp.knn_weights(v)
+        errs = {}
+        errs["w"] = rel(w.toarray(), orc.dense_weights(nbr, wt, n))
+        errs["deform"] = rel(nicp.deform(P, w, v).cpu().numpy(), orc.deform(P, nbr, wt, v))
+        r_o = orc.min_func(P, nbr, wt, v, edges, nn, c, compat)
+        J_o = orc.d_min_func(P, nbr, wt, v, edges, nn, c, compat)
+        errs["r"] = rel(nicp.residual(P, w, v, edges, nn, c, compat=compat).cpu().numpy(), r_o)
+        pv, pu = rng.standard_normal(P.shape), rng.standard_normal(r_o.shape)
+        errs["Jv"] = rel(nicp.jvp(P, w, v, edges, c, pv, compat=compat).cpu().numpy(), J_o @ pv)
+        errs["JTu"] = rel(nicp.jtvp(P, w, v, edges, c, pu, compat=compat).cpu().numpy(), J_o.T @ pu)
+        # one LM step of the product against the dense twin of its loop
+        P1, st = nicp.solve(P, w, v, edges, nn, c, compat=compat, opts=dict(max_lm_iters=1, cg_tol=1e-13))
+        tr = []
+        P1o = orc.lm_dense(P, nbr, wt, v, edges, nn, c, compat, steps=1, trace=tr)
+        P1o = P1o[0] if isinstance(P1o, tuple) else P1o
+        errs["lm_step"] = rel(P1.cpu().numpy() - P, np.asarray(P1o) - P) if np.abs(np.asarray(P1o) - P).max() > 0 else 0.0
+        note = ""
+        if errs["lm_step"] >= 1e-7:
+            # the dense solve is itself only good to cond * eps: price the comparison against the system's condition
+            col2 = (J_o * J_o).sum(0)
+            d2 = np.where(col2 > 0, col2, 1.0)
+            H = J_o.T @ J_o + tr[-1]["lam"] * np.diag(d2)
+            dsc = 1.0 / np.sqrt(np.diag(H))
+            cond = np.linalg.cond(H * dsc[:, None] * dsc[None, :])
+            note = " cond(scaled H) %.1e" % cond
+            # who is right?  refine the dense solve (residuals in extended precision) and compare both against that
+            g_o = J_o.T @ r_o
+            Hl, bl = H.astype(np.longdouble), (-g_o).astype(np.longdouble)
+            x = np.linalg.solve(H, -g_o)
+            for _ in range(5):
+                res = np.asarray(bl - Hl @ x.astype(np.longdouble), dtype=np.float64)
+                x = x + np.linalg.solve(H, res)
+            e_gpu, e_dense = rel(P1.cpu().numpy() - P, x), rel(tr[-1]["delta"], x)
+            note += " vs refined solve: gpu %.1e, dense %.1e" % (e_gpu, e_dense)
+            if len(tr) == 1 and e_gpu < 1e-6:
+                errs["lm_step"] = e_gpu
+        ok = all(e < 1e-6 for e in errs.values())
+        bad += 0 if ok else 1
+        print("%4d %-5s dim %d n %3d edges %3d compat %d c %s  %s" % (case, "ok" if ok else "FAIL", dim, n, len(edges), compat, c,
+              " ".join("%s %.1e" % kv for kv in errs.items()) + note), flush=True)
+    print("cases %d, failures %d" % (args.cases, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
