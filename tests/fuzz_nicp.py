@@ -24,6 +24,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--solve", action="store_true", help="whole solves in the self-consistent mode against scipy's leastsq on the "
+                                                        "oracle (energy and deformed vertices to 1e-6) instead of the operators")
     args = ap.parse_args()
     import torch
     from icp_amd import nicp
@@ -55,6 +57,26 @@ def main():
         nbr, wt = orc.knn_weights(v)
         w = nicp.knn_weights(v)
         errs = {}
+        if args.solve:
+            from scipy import optimize
+            if n > 40 or c[1] < 30 or c[2] < 3:      # weakly regularised fits have flat minima: nothing to compare at 1e-6
+                continue
+            P0 = np.append(np.tile(np.append(np.eye(dim).ravel(), np.zeros(dim)), n), np.zeros(ng))
+            lsq = optimize.leastsq(lambda q: orc.min_func(q, nbr, wt, v, edges, nn, c, False), P0,
+                                   Dfun=lambda q: orc.d_min_func(q, nbr, wt, v, edges, nn, c, False), full_output=1,
+                                   ftol=1e-13, xtol=1e-13, maxfev=3000)
+            e_ref = float((lsq[2]["fvec"] ** 2).sum())
+            dd_ref = orc.deform(lsq[0], nbr, wt, v)
+            Pg, st = nicp.solve(P0, w, v, edges, nn, c, compat=False, opts=dict(ftol=1e-13, xtol=1e-13, max_lm_iters=3000))
+            errs["energy"] = abs(st["err"] - e_ref) / (e_ref + 1e-300)
+            errs["deformed"] = float(np.abs(nicp.deform(Pg, w, v).cpu().numpy() - dd_ref).max() / np.abs(v).max())
+            limit = lsq[4] == 5 or st["info"] == 5      # an evaluation limit on either side: no minimiser to compare
+            ok = limit or (errs["energy"] < 1e-6 and errs["deformed"] < 1e-6)
+            bad += 0 if ok else 1
+            print("%4d %-5s solve dim %d n %3d edges %3d c %s  leastsq ier %d nfev %d | gpu info %d lm %d cg %d  %s" %
+                  (case, ("skip" if limit else "ok") if ok else "FAIL", dim, n, len(edges), c, lsq[4], lsq[2]["nfev"], st["info"], st["lm_iters"], st["cg_iters"],
+                   " ".join("%s %.1e" % kv for kv in errs.items())), flush=True)
+            continue
         errs["w"] = rel(w.toarray(), orc.dense_weights(nbr, wt, n))
         errs["deform"] = rel(nicp.deform(P, w, v).cpu().numpy(), orc.deform(P, nbr, wt, v))
         r_o = orc.min_func(P, nbr, wt, v, edges, nn, c, compat)
