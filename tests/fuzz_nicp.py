@@ -24,6 +24,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--ext", action="store_true", help="the extended energy (per-vertex / per-edge multipliers, landmarks): residual, "
+                                                      "J v, J^T u and one LM step against the oracle's extension")
     ap.add_argument("--solve", action="store_true", help="whole solves in the self-consistent mode against scipy's leastsq on the "
                                                         "oracle (energy and deformed vertices to 1e-6) instead of the operators")
     args = ap.parse_args()
@@ -57,6 +59,40 @@ def main():
         nbr, wt = orc.knn_weights(v)
         w = nicp.knn_weights(v)
         errs = {}
+        if args.ext:
+            fit_w = rng.uniform(0.2, 3.0, n) if rng.integers(0, 2) else None
+            rigid_w = rng.uniform(0.2, 3.0, n) if rng.integers(0, 2) else None
+            edge_w = rng.uniform(0.2, 3.0, len(edges)) if rng.integers(0, 2) else None
+            nl = int(rng.integers(0, max(2, n // 4)))
+            lm_v = rng.choice(n, nl, replace=False).astype(np.int32) if nl else None
+            lm_p = (v[lm_v] + rng.standard_normal((nl, dim)) * 0.05 * np.abs(v).max()) if nl else None
+            c_land = float(rng.choice([0.5, 5.0, 50.0]))
+            w.set_weights(edges, fit_w, rigid_w, edge_w)
+            w.set_landmarks(edges, lm_v, lm_p, c_land)
+            kw = dict(fit_w=fit_w, rigid_w=rigid_w, edge_w=edge_w, lm_vertex=lm_v, lm_pos=lm_p, c_land=c_land)
+            r_o = orc.min_func_ext(P, nbr, wt, v, edges, nn, c, **kw)
+            J_o = orc.d_min_func_ext(P, nbr, wt, v, edges, nn, c, **kw)
+            errs["r"] = rel(nicp.residual(P, w, v, edges, nn, c, compat=False).cpu().numpy(), r_o)
+            pv, pu = rng.standard_normal(P.shape), rng.standard_normal(r_o.shape)
+            errs["Jv"] = rel(nicp.jvp(P, w, v, edges, c, pv, compat=False).cpu().numpy(), J_o @ pv)
+            errs["JTu"] = rel(nicp.jtvp(P, w, v, edges, c, pu, compat=False).cpu().numpy(), J_o.T @ pu)
+            # one LM step (first trial, lam = 1e-3, D = column norms) against the refined dense solve
+            P1, st = nicp.solve(P, w, v, edges, nn, c, compat=False, opts=dict(max_lm_iters=1, cg_tol=1e-13))
+            col2 = (J_o * J_o).sum(0)
+            H = J_o.T @ J_o + 1e-3 * np.diag(np.where(col2 > 0, col2, 1.0))
+            g_o = J_o.T @ r_o
+            x = np.linalg.solve(H, -g_o)
+            for _ in range(4):
+                x = x + np.linalg.solve(H, np.asarray((-g_o).astype(np.longdouble) - H.astype(np.longdouble) @ x.astype(np.longdouble),
+                                                      dtype=np.float64))
+            r1 = orc.min_func_ext(P + x, nbr, wt, v, edges, nn, c, **kw)
+            first_trial_accepted = st["nfev"] == 2
+            errs["lm_step"] = rel(P1.cpu().numpy() - P, x) if first_trial_accepted and float(r1 @ r1) < float(r_o @ r_o) else 0.0
+            ok = all(e < 1e-6 for e in errs.values())
+            bad += 0 if ok else 1
+            print("%4d %-5s ext dim %d n %3d edges %3d landmarks %2d c %s  %s" % (case, "ok" if ok else "FAIL", dim, n, len(edges), nl, c,
+                  " ".join("%s %.1e" % kv for kv in errs.items())), flush=True)
+            continue
         if args.solve:
             from scipy import optimize
             if n > 40 or c[1] < 30 or c[2] < 3:      # weakly regularised fits have flat minima: nothing to compare at 1e-6
