@@ -78,20 +78,21 @@ def main():
         # one tight cluster -- its transforms then drift apart for reasons that have nothing to do with the search;
         # so the check is path-consistent instead, like bench.py's config.check: the correspondences of iteration K
         # of the fused loop must be the full scan's answer for the positions its own iteration K-1 produced)
-        B = rigid.rigid_icp(src, tgt, 0.0, run, use_tol=False, force_grid=True, want_idx=True)
+        sq = bool(rng.integers(0, 4) == 0)     # the C++ command's comparison of rounded roots (two-pass search)
+        B = rigid.rigid_icp(src, tgt, 0.0, run, use_tol=False, force_grid=True, want_idx=True, compare_sqrt=sq)
         if run > 1:
-            prev = rigid.rigid_icp(src, tgt, 0.0, run - 1, use_tol=False, force_grid=True)["T"]
+            prev = rigid.rigid_icp(src, tgt, 0.0, run - 1, use_tol=False, force_grid=True, compare_sqrt=sq)["T"]
             ss = rigid.apply_transform(src, prev[:dim, :dim].contiguous(), prev[dim, :dim].contiguous())
         else:
             ss = src
-        ref = rigid.closest_indices(ss, tgt, force_brute=True)
+        ref = rigid.closest_indices(ss, tgt, force_brute=True, compare_sqrt=sq)
         nidx = int((ref != B["idx"]).sum())
-        again = rigid.rigid_icp(src, tgt, 0.0, run, use_tol=False, force_grid=True, want_idx=True)
+        again = rigid.rigid_icp(src, tgt, 0.0, run, use_tol=False, force_grid=True, want_idx=True, compare_sqrt=sq)
         same = torch.equal(again["T"], B["T"]) and torch.equal(again["idx"], B["idx"]) and torch.equal(again["err_hist"], B["err_hist"])
         ok = nidx == 0 and same
         bad += 0 if ok else 1
-        print("%4d %-5s loop dim %d n %7d m %7d tgt %-8s run %d  idx_diff_vs_scan %d reproducible %d" %
-              (case, "ok" if ok else "FAIL", dim, n, m, kt, run, nidx, same), flush=True)
+        print("%4d %-5s loop dim %d n %7d m %7d tgt %-8s run %d sqrt %d  idx_diff_vs_scan %d reproducible %d" %
+              (case, "ok" if ok else "FAIL", dim, n, m, kt, run, sq, nidx, same), flush=True)
     for case in range(0 if args.loop else args.cases):
         dim = int(rng.choice([2, 3]))
         n = int(np.exp(rng.uniform(0, np.log(args.max_n))))
