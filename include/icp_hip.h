@@ -258,7 +258,7 @@ typedef struct nicp_solve_opts {
     double ftol, xtol, gtol; /* MINPACK-style relative tolerances; leastsq defaults 1.49012e-8, 1.49012e-8, 0 */
     double lambda0;          /* initial Levenberg-Marquardt damping (1e-3) */
     double cg_tol;           /* relative residual |r| / |g| of the inner conjugate-gradient solve; <= 0 (default): automatic,
-                                min(1e-4, sqrt(min(ftol, xtol))).  Below 1e-6 the preconditioned residual r.z / r0.z0 is
+                                min(1e-3, 10 sqrt(min(ftol, xtol))).  Below 1e-6 the preconditioned residual r.z / r0.z0 is
                                 held to the same bound as well: on the badly scaled systems of the reference's constants
                                 a small |r| alone leaves the step up to 2e-6 from the exact one */
     int max_lm_iters;        /* cap on the LM iterations; <= 0 (default): none beyond leastsq's own limit of
