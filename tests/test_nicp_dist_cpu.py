@@ -30,9 +30,9 @@ def _mesh(nx=9, ny=8, seed=3):
     return v, edges, tgt, nbr, wt, P, nn
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_partition_covers_and_orders(world):
-    v, edges, tgt, nbr, wt, P, nn = _mesh()
+@pytest.mark.parametrize("world,nx,ny", [(2, 9, 8), (3, 9, 8), (5, 13, 11), (8, 14, 12)])
+def test_partition_covers_and_orders(world, nx, ny):
+    v, edges, tgt, nbr, wt, P, nn = _mesh(nx, ny)
     shards, owner = nd.make_shards(v, nbr, wt, edges, world)
     n = v.shape[0]
     assert sorted(np.concatenate([s.owned for s in shards]).tolist()) == list(range(n))
@@ -50,9 +50,10 @@ def test_partition_covers_and_orders(world):
     assert e_owned == len(edges)                                                # every edge row owned exactly once
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_operator_assembles_to_global(world):
-    v, edges, tgt, nbr, wt, P, nn = _mesh()
+@pytest.mark.parametrize("world,nx,ny", [(2, 9, 8), (3, 9, 8), (8, 14, 12)])
+def test_sharded_operator_assembles_to_global(world, nx, ny):
+    """(8 ranks = the C5 configuration's rank count: shards with several neighbours each, halos from up to 7 ranks)"""
+    v, edges, tgt, nbr, wt, P, nn = _mesh(nx, ny)
     n, S, NG = v.shape[0], 12, 6
     J = orc.d_min_func(P, nbr, wt, v, edges, nn, C, compat=False)
     r = orc.min_func(P, nbr, wt, v, edges, nn, C, compat=False)
