@@ -128,12 +128,14 @@ def _assemble(res, n):
     return P, dd
 
 
-def test_world2_solve_matches_single():
+@pytest.mark.parametrize("world", [2, 4])
+def test_world2_solve_matches_single(world):
+    """(world 4: every rank has halos from several others; all ranks share the test box's one GPU)"""
     nx, ny = 14, 12
     v, edges, tgt, nbr, wt, nn = _problem(nx, ny)
     n = v.shape[0]
     P_ref, st_ref = _single(v, edges, nbr, wt, nn, TIGHT)
-    res = _run_world(2, nx, ny, "solve")
+    res = _run_world(world, nx, ny, "solve")
     P, dd = _assemble(res, n)
     for o in res:
         assert o["n_halo"] > 0 and o["calls"]["exchange"] > 0 and o["calls"]["allreduce"] > 0
