@@ -73,7 +73,6 @@ static int cg_chunk_size() {
     }();
     return v;
 }
-#define kCgChunk (cg_chunk_size())
 
 template <int DIM>
 struct Lay {
@@ -3381,7 +3380,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             ICP_HIP_CHECK(hipGetLastError());
             // `count` CG iterations.  The damping enters as the vector lam*D^2 (w.lamd2, multiplier 1.0: the same
             // bits as lam * d2 * p), so no kernel argument below changes during a solve and the single-GPU
-            // path can replay kCgChunk iterations as one hipGraph (6 launches each, launch-bound on small meshes).
+            // path can replay cg_chunk_size() iterations as one hipGraph (6 launches each, launch-bound on small meshes).
             auto cg_iterations = [&](int count) -> int {
                 for (int k = 0; k < count; ++k) {
                     mark(0);
@@ -3426,7 +3425,7 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 int rc = ICP_OK;
                 hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
                 if (e == hipSuccess) {
-                    rc = cg_iterations(kCgChunk);
+                    rc = cg_iterations(cg_chunk_size());
                     e = hipStreamEndCapture(st, &captured);
                 }
                 ctx->stream = st = user;
@@ -3460,16 +3459,16 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 int done_it = 0;
                 ICP_HIP_CHECK(hipEventRecord(ev[7], st));
                 while (done_it < iters) {
-                    if (cg.exec && iters - done_it >= kCgChunk) {
+                    if (cg.exec && iters - done_it >= cg_chunk_size()) {
                         ICP_HIP_CHECK(hipEventRecord(ctx->side_ev, st));
                         ICP_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));
                         ICP_HIP_CHECK(hipGraphLaunch(cg.exec, ctx->side));
                         ICP_HIP_CHECK(hipEventRecord(ctx->side_ev, ctx->side));
                         ICP_HIP_CHECK(hipStreamWaitEvent(st, ctx->side_ev, 0));
-                        done_it += kCgChunk;
+                        done_it += cg_chunk_size();
                         prof->graph_replay = 1;
                     } else {
-                        const int cnt = std::min(kCgChunk, iters - done_it);
+                        const int cnt = std::min(cg_chunk_size(), iters - done_it);
                         if (int rc2 = cg_iterations(cnt)) return rc2;
                         done_it += cnt;
                     }
@@ -3490,8 +3489,8 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             }
             int cg_done = 0;
             for (int ci = 0; ci < o.max_cg_iters && !cg_done;) {
-                const int chunk = std::min(kCgChunk, o.max_cg_iters - ci);
-                if (cg.exec && chunk == kCgChunk) {
+                const int chunk = std::min(cg_chunk_size(), o.max_cg_iters - ci);
+                if (cg.exec && chunk == cg_chunk_size()) {
                     ICP_HIP_CHECK(hipEventRecord(ctx->side_ev, st));
                     ICP_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));
                     ICP_HIP_CHECK(hipGraphLaunch(cg.exec, ctx->side));
