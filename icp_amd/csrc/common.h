@@ -79,6 +79,7 @@ struct GridParams {
     double inv_h;
     int bits;      // cells per axis = 1 << bits
     int dim;
+    int open;      // bit 2a / 2a+1: the first / last column of axis a is unbounded outwards (robust extents, grid.hip)
 };
 struct GridBuild {
     GridParams gp;

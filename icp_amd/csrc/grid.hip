@@ -22,6 +22,9 @@
 //
 // Targets containing NaN/inf are refused by the builder (flag) and the caller falls back
 // to the brute-force kernels, whose "first NaN wins" rule needs a full scan anyway.
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 
 namespace icp {
@@ -32,6 +35,7 @@ constexpr int GB = 256;
 struct BBox {
     double mn[3], mx[3];
     unsigned long long bad;
+    double qlo[3], qhi[3];  // per-axis 1 % / 99 % order statistics of a fixed-stride sample (quantile_kernel)
 };
 
 template <int DIM>
@@ -124,6 +128,43 @@ __device__ __forceinline__ void cell_of(const double *p, const GridParams &gp, i
         const double f = (p[a] - gp.mn[a]) * gp.inv_h;
         int ci = f >= 0.0 ? (f < (double)top ? (int)f : top) : 0;  // NaN -> 0
         c[a] = ci;
+    }
+}
+
+// Robust extents (grid_build_into): the grid may cover less than the bounding box; points beyond it are clamped into
+// the first / last column by cell_of, so those columns are UNBOUNDED outwards and the gap from a query to such a column
+// must not count its outer face.  g / gh = signed gaps to the low / high face of column x of axis a (ncl columns).
+__device__ __forceinline__ void open_sides(const GridParams &gp, int a, int x, int ncl, double &g, double &gh) {
+    if (x <= 0 && ((gp.open >> (2 * a)) & 1)) g = -__builtin_inf();
+    if (x >= ncl - 1 && ((gp.open >> (2 * a + 1)) & 1)) gh = -__builtin_inf();
+}
+
+// Block a sorts the a-th coordinate of ns <= 4096 points taken at a fixed stride (bitonic network in LDS) and writes its
+// k-th smallest and k-th largest value: the quantiles that set the extents of the grid.  Deterministic.
+constexpr int kQuantSamples = 4096;
+__global__ __launch_bounds__(1024) void quantile_kernel(const double *__restrict__ p, int64_t stride, int ns, int dim, int k,
+                                                        BBox *__restrict__ out) {
+    __shared__ double v[kQuantSamples];
+    const int a = blockIdx.x;
+    for (int i = threadIdx.x; i < kQuantSamples; i += blockDim.x)
+        v[i] = i < ns ? p[(int64_t)i * stride * dim + a] : __builtin_inf();
+    __syncthreads();
+    for (int size = 2; size <= kQuantSamples; size <<= 1)
+        for (int str = size >> 1; str > 0; str >>= 1) {
+            for (int t = threadIdx.x; t < kQuantSamples / 2; t += blockDim.x) {
+                const int lo = (t / str) * 2 * str + (t % str), hi = lo + str;
+                const bool up = ((lo & size) == 0);
+                const double x = v[lo], y = v[hi];
+                if ((x > y) == up) {
+                    v[lo] = y;
+                    v[hi] = x;
+                }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x == 0) {
+        out->qlo[a] = v[k];
+        out->qhi[a] = v[ns - 1 - k];
     }
 }
 
@@ -417,7 +458,8 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 sp[a][o] = okc[a][o] ? (DIM == 3 ? spread3((uint32_t)x) : spread2((uint32_t)x)) << a : 0u;
                 const double lo = gp.mn[a] + (double)x * hl, hi = gp.mn[a] + (double)(x + 1) * hl;
                 double g = lo - s[a] - sl;
-                const double gh = s[a] - hi - sl;
+                double gh = s[a] - hi - sl;
+                open_sides(gp, a, x, ncl, g, gh);
                 g = gh > g ? gh : g;
                 g = g > 0.0 ? g : 0.0;
                 g2[a][o] = g * g;
@@ -601,7 +643,8 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double *__restrict
                     const double sl = slack_h + (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
                     const double lo = gp.mn[a] + (double)x[a] * hl, hi = gp.mn[a] + (double)(x[a] + 1) * hl;
                     double g = lo - s[a] - sl;
-                    const double gh = s[a] - hi - sl;
+                    double gh = s[a] - hi - sl;
+                    open_sides(gp, a, x[a], ncl, g, gh);
                     g = gh > g ? gh : g;
                     g = g > 0.0 ? g : 0.0;
                     bound = bound + g * g;   // same association as the per-lane pass: ((gx + gy) + gz)
@@ -759,7 +802,8 @@ __global__ __launch_bounds__(GB) void grid_knn_kernel(const double *__restrict__
                     const double sl = slack_h + (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
                     const double lo = gp.mn[a] + (double)x[a] * hl, hi = gp.mn[a] + (double)(x[a] + 1) * hl;
                     double g = lo - s[a] - sl;
-                    const double gh = s[a] - hi - sl;
+                    double gh = s[a] - hi - sl;
+                    open_sides(gp, a, x[a], ncl, g, gh);
                     g = gh > g ? gh : g;
                     g = g > 0.0 ? g : 0.0;
                     bound = bound + g * g;
@@ -871,10 +915,36 @@ int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBui
     else hipLaunchKernelGGL(bbox_kernel<2>, dim3(nb), dim3(GB), 0, st, tgt, m, part);
     hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(448), 0, st, (const double *)part, nb, dbox);
     ICP_HIP_CHECK(hipGetLastError());
+    // Robust extents.  A uniform grid over the bounding box degenerates when a few points lie far out (one outlier at
+    // 1e6 puts a whole unit-size cloud into ONE cell: the search is then a full scan per query) and wastes resolution on
+    // thin tails (a Gaussian's bounding box is +-5 sigma, 99.9 % of it lies within +-3.3).  So the grid spans, per axis,
+    // the 1 % .. 99 % order statistics of a fixed-stride sample of 4096 points widened by `clip` of their distance on each side
+    // (and never more than the bounding box); points beyond are clamped into the border columns, which the searches
+    // treat as unbounded outwards (open_sides).  Exactness does not depend on where the extents are.
+    static const double clip = getenv("ICP_GRID_CLIP") ? atof(getenv("ICP_GRID_CLIP")) : 0.3;
+    const int ns = (int)std::min<int64_t>(kQuantSamples, m);
+    const bool robust = clip >= 0.0 && ns >= 64;
+    if (robust)  // (same stream, after bbox_final_kernel: it adds its six numbers to the same record)
+        hipLaunchKernelGGL(quantile_kernel, dim3(dim), dim3(1024), 0, st, tgt, m / ns, ns, dim, std::max(1, ns / 100), dbox);
+    ICP_HIP_CHECK(hipGetLastError());
     BBox hb;
     ICP_HIP_CHECK(hipMemcpyAsync(&hb, dbox, sizeof(BBox), hipMemcpyDeviceToHost, st));
     ICP_HIP_CHECK(hipStreamSynchronize(st));
     if (hb.bad) return ICP_OK;  // NaN / inf in the target: caller uses the brute-force scan
+    int open = 0;
+    for (int a = 0; robust && a < dim; ++a) {
+        const double wdt = hb.qhi[a] - hb.qlo[a];
+        if (!(wdt > 0.0) || !(wdt < __builtin_inf())) continue;  // (nearly) constant or non-finite sample: keep the bounding box
+        const double lo = hb.qlo[a] - clip * wdt, hi = hb.qhi[a] + clip * wdt;
+        if (lo > hb.mn[a]) {
+            hb.mn[a] = lo;
+            open |= 1 << (2 * a);
+        }
+        if (hi < hb.mx[a]) {
+            hb.mx[a] = hi;
+            open |= 1 << (2 * a + 1);
+        }
+    }
     double ext = 0.0;
     for (int a = 0; a < dim; ++a) {
         const double e = hb.mx[a] - hb.mn[a];
@@ -897,6 +967,7 @@ int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBui
     }
     gp.bits = bits;
     gp.dim = dim;
+    gp.open = open;
     gp.h = ext / (double)(1 << bits);
     gp.h *= 1.0 + 0x1p-30;  // the far face of the last cell lies beyond the largest coordinate
     gp.inv_h = 1.0 / gp.h;

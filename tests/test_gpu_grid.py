@@ -47,6 +47,16 @@ def clouds():
     line[:, 0] = np.linspace(0, 1, 5000)
     out["collinear"] = (rng.standard_normal((2000, 3)), line)
     out["tiny_target"] = (rng.standard_normal((3000, 3)), rng.standard_normal((3, 3)))
+    # far outliers on both sides: the grid spans the bulk only (robust extents), the outliers live in the unbounded
+    # border columns; queries among them, beyond them and in the bulk
+    bulk = rng.standard_normal((60000, 3))
+    bulk[rng.integers(0, 60000, 40)] *= 1e6
+    q = rng.standard_normal((20000, 3))
+    q[:200] *= 1e6
+    q[200:400] = bulk[rng.integers(0, 60000, 200)] * (1 + 1e-9)
+    out["far_outliers"] = (q, bulk)
+    # heavy tails: a Cauchy cloud has no meaningful bounding box at all
+    out["cauchy2"] = (rng.standard_cauchy((15000, 2)), rng.standard_cauchy((50000, 2)))
     return out
 
 
@@ -198,3 +208,27 @@ def test_deferred_counters_survive_early_stop_and_resizing(rigid):
     b = rigid.rigid_icp(big_s, big_t, 0.10, 30, want_idx=True, force_brute=True)
     assert np.array_equal(a["idx"].cpu().numpy(), b["idx"].cpu().numpy())
     check()
+
+
+def test_one_far_outlier_does_not_turn_the_grid_into_a_scan(rigid):
+    """A single target point at 1e7 used to stretch the grid over the bounding box: the whole cloud fell into one cell
+    and every query scanned every target (seconds).  With the extents taken from quantiles the search stays a grid
+    search: same answer as the scan, and at least 20x faster than it."""
+    import time
+    import torch
+    rng = np.random.default_rng(5)
+    tgt = rng.standard_normal((300000, 3))
+    tgt[12345] = [1e7, -1e7, 1e7]
+    src = rng.standard_normal((300000, 3))
+    rigid.closest_indices(src[:1000], tgt, force_grid=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gi = rigid.closest_indices(src, tgt, force_grid=True)
+    torch.cuda.synchronize()
+    t_grid = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    bi = rigid.closest_indices(src, tgt, force_brute=True)
+    torch.cuda.synchronize()
+    t_brute = time.perf_counter() - t0
+    assert torch.equal(gi, bi)
+    assert t_grid * 20 < t_brute, (t_grid, t_brute)
