@@ -23,6 +23,8 @@
 // Targets containing NaN/inf are refused by the builder (flag) and the caller falls back
 // to the brute-force kernels, whose "first NaN wins" rule needs a full scan anyway.
 #include <algorithm>
+#include <cmath>
+#include <cstdio>
 #include <vector>
 
 #include "common.h"
@@ -36,6 +38,7 @@ struct BBox {
     double mn[3], mx[3];
     unsigned long long bad;
     double qlo[3], qhi[3];  // per-axis 1 % / 99 % order statistics of a fixed-stride sample (quantile_kernel)
+    double pairs[16];       // sample pairs sharing a cell of side ext / 2^(B - l), l = 0 .. B (occupancy_kernel)
 };
 
 template <int DIM>
@@ -166,6 +169,75 @@ __global__ __launch_bounds__(1024) void quantile_kernel(const double *__restrict
         out->qlo[a] = v[k];
         out->qhi[a] = v[ns - 1 - k];
     }
+}
+
+// How fine should the grid be?  What a query pays for is the population of the cells it visits, and that depends on how
+// the points fill space, not only on how many there are: a volume-filling cloud, a Gaussian and a scanned surface of
+// the same size want cells of different sizes (measured: 2^20 points, best finest level 6 / 7 / 8+ bits per axis).  The
+// density-weighted mean population of a cell is 1 + N * P(two random points share a cell), and that probability is
+// estimated here at EVERY level at once from the pairs of the sample: the samples' Morton codes at the finest
+// conceivable level (B bits per axis) are sorted, and two samples share a level-l cell iff their codes agree above
+// dim*l bits -- in sorted order those are runs.  pairs[l] = number of sample pairs in a common level-l cell (each
+// element counts at most 32 predecessors: beyond that the level is far too coarse anyway).
+constexpr int kOccB3 = 9, kOccB2 = 13;
+__global__ __launch_bounds__(1024) void occupancy_kernel(const double *__restrict__ p, int64_t stride, int ns, int dim,
+                                                         double clip, BBox *__restrict__ io) {
+    __shared__ uint32_t code[kQuantSamples];
+    __shared__ unsigned int pairs[16];
+    const int B = dim == 3 ? kOccB3 : kOccB2;
+    double mn[3] = {0, 0, 0}, ext = 0.0;
+    for (int a = 0; a < dim; ++a) {  // the extents grid_build_into will choose (same arithmetic)
+        double lo = io->mn[a], hi = io->mx[a];
+        const double wdt = io->qhi[a] - io->qlo[a];
+        if (wdt > 0.0 && wdt < __builtin_inf()) {
+            const double l2 = io->qlo[a] - clip * wdt, h2 = io->qhi[a] + clip * wdt;
+            lo = l2 > lo ? l2 : lo;
+            hi = h2 < hi ? h2 : hi;
+        }
+        mn[a] = lo;
+        ext = hi - lo > ext ? hi - lo : ext;
+    }
+    if (!(ext > 0.0)) ext = 1.0;
+    const double inv_h = 1.0 / (ext / (double)(1 << B) * (1.0 + 0x1p-30));
+    const int top = (1 << B) - 1;
+    if (threadIdx.x < 16) pairs[threadIdx.x] = 0u;
+    for (int i = threadIdx.x; i < kQuantSamples; i += blockDim.x) {
+        uint32_t c = 0xffffffffu;
+        if (i < ns) {
+            int cell[3] = {0, 0, 0};
+            for (int a = 0; a < dim; ++a) {
+                const double f = (p[(int64_t)i * stride * dim + a] - mn[a]) * inv_h;
+                cell[a] = f >= 0.0 ? (f < (double)top ? (int)f : top) : 0;
+            }
+            c = dim == 3 ? (spread3(cell[0]) | (spread3(cell[1]) << 1) | (spread3(cell[2]) << 2)) : (spread2(cell[0]) | (spread2(cell[1]) << 1));
+        }
+        code[i] = c;
+    }
+    __syncthreads();
+    for (int size = 2; size <= kQuantSamples; size <<= 1)
+        for (int str = size >> 1; str > 0; str >>= 1) {
+            for (int t = threadIdx.x; t < kQuantSamples / 2; t += blockDim.x) {
+                const int lo = (t / str) * 2 * str + (t % str), hi = lo + str;
+                const bool up = ((lo & size) == 0);
+                const uint32_t x = code[lo], y = code[hi];
+                if ((x > y) == up) {
+                    code[lo] = y;
+                    code[hi] = x;
+                }
+            }
+            __syncthreads();
+        }
+    for (int l = 0; l <= B; ++l) {
+        const int sh = dim * l;
+        unsigned int cnt = 0;
+        for (int i = threadIdx.x; i < ns; i += blockDim.x) {
+            const uint32_t ci = code[i] >> sh;
+            for (int j = i - 1; j >= 0 && i - j <= 32 && (code[j] >> sh) == ci; --j) ++cnt;
+        }
+        if (cnt) atomicAdd(&pairs[l], cnt);
+    }
+    __syncthreads();
+    if (threadIdx.x <= B) io->pairs[threadIdx.x] = (double)pairs[threadIdx.x];
 }
 
 template <int DIM>
@@ -930,6 +1002,9 @@ int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBui
     const bool robust = clip >= 0.0 && ns >= 64 && !stable;  // (a sorted SOURCE only needs an order: any extents do)
     if (robust)  // (same stream, after bbox_final_kernel: it adds its six numbers to the same record)
         hipLaunchKernelGGL(quantile_kernel, dim3(dim), dim3(1024), 0, st, tgt, m / ns, ns, dim, std::max(1, ns / 100), dbox);
+    static const double occ_target = getenv("ICP_GRID_OCC") ? atof(getenv("ICP_GRID_OCC")) : 5.0;
+    const bool adaptive = robust && env_bits() <= 0 && occ_target > 0.0;
+    if (adaptive) hipLaunchKernelGGL(occupancy_kernel, dim3(1), dim3(1024), 0, st, tgt, m / ns, ns, dim, clip, dbox);
     ICP_HIP_CHECK(hipGetLastError());
     BBox hb;
     ICP_HIP_CHECK(hipMemcpyAsync(&hb, dbox, sizeof(BBox), hipMemcpyDeviceToHost, st));
@@ -963,7 +1038,25 @@ int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBui
         const int maxbits = dim == 3 ? 8 : 12;
         while (bits < maxbits && (double)(1ull << (dim * (bits + 1))) <= 4.0 * (double)m) ++bits;
     }
+    if (adaptive) {
+        // the level whose estimated density-weighted cell population, 1 + N * pairs / (S choose 2), is closest to the
+        // target (5: measured best on volume-filling, Gaussian and surface clouds of 2^18 .. 2^22 points)
+        const int B = dim == 3 ? kOccB3 : kOccB2, maxbits = dim == 3 ? 8 : 12;
+        const double denom = 0.5 * (double)ns * (double)(ns - 1);
+        double best_d = __builtin_inf();
+        for (int b = 1; b <= maxbits; ++b) {
+            const double occ = 1.0 + (double)m * hb.pairs[B - b] / denom;
+            const double d = std::fabs(std::log(occ / occ_target));
+            if (d <= best_d) {   // ties: the finer level
+                best_d = d;
+                bits = b;
+            }
+        }
+    }
     if (bits > (dim == 3 ? 9 : 14)) bits = dim == 3 ? 9 : 14;
+    if (getenv("ICP_GRID_TRACE"))
+        std::fprintf(stderr, "grid_build: m %lld dim %d bits %d (%s) open %d ext %.6g\n", (long long)m, dim, bits,
+                     adaptive ? "from the sample's cell populations" : "size rule / ICP_GRID_BITS", open, ext);
     GridParams gp;
     for (int a = 0; a < 3; ++a) {
         gp.mn[a] = a < dim ? hb.mn[a] : 0.0;
