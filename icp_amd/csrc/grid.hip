@@ -227,14 +227,26 @@ __global__ __launch_bounds__(1024) void occupancy_kernel(const double *__restric
             }
             __syncthreads();
         }
-    for (int l = 0; l <= B; ++l) {
-        const int sh = dim * l;
-        unsigned int cnt = 0;
-        for (int i = threadIdx.x; i < ns; i += blockDim.x) {
-            const uint32_t ci = code[i] >> sh;
-            for (int j = i - 1; j >= 0 && i - j <= 32 && (code[j] >> sh) == ci; --j) ++cnt;
+    // one walk over the (at most 32) predecessors of every sample serves all levels: two codes share a level-l cell iff
+    // they agree above dim*l bits, i.e. from level ceil(bitlength(a ^ b) / dim) upwards
+    unsigned int cnt[14];
+#pragma unroll
+    for (int l = 0; l < 14; ++l) cnt[l] = 0u;
+    for (int i = threadIdx.x; i < ns; i += blockDim.x) {
+        const uint32_t ci = code[i];
+        for (int d = 1; d <= 32 && i - d >= 0; ++d) {
+            const uint32_t x = ci ^ code[i - d];
+            const int nb = x ? 32 - __clz((int)x) : 0;
+            const int lmin = (nb + dim - 1) / dim;
+#pragma unroll
+            for (int l = 0; l < 14; ++l) cnt[l] += l >= lmin ? 1u : 0u;
         }
-        if (cnt) atomicAdd(&pairs[l], cnt);
+    }
+#pragma unroll
+    for (int l = 0; l < 14; ++l) {
+        unsigned int v = cnt[l];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&pairs[l], v);
     }
     __syncthreads();
     if (threadIdx.x <= B) io->pairs[threadIdx.x] = (double)pairs[threadIdx.x];
