@@ -710,6 +710,40 @@ extern "C" int icp_shard_apply_err(icp_ctx *ctx, const double *src, const double
     return apply_err(ctx, 1, src, tgt, idx, n, dim, R_dev, t_dev, ss_out, err_out_dev, nullptr);
 }
 
+// The two one-time structures of a run: the search grid over the target and the Morton order of the source.  They are
+// independent, and each is a chain of mostly small kernels with one host read-back in the middle, so the source's
+// goes first, on the context's side stream, and keeps running there (counting, sorting, gathering) while the
+// target's statistics kernels -- single-block sorts of a sample -- and its read-back happen on the main stream;
+// the main stream waits for the side stream at the end.  2^20 x 2^20: set-up 0.78 -> see DESIGN.md 3.1b.
+namespace icp {
+static int build_grids(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim, unsigned flags,
+                       GridBuild &grid, GridBuild &qsort) {
+    if (!grid_worthwhile(n, m, flags)) return ICP_OK;
+    const bool sort_source = n >= 32768;
+    bool side_ok = sort_source;
+    if (side_ok && !ctx->side && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) side_ok = false;
+    if (side_ok && !ctx->side_ev && hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming) != hipSuccess) side_ok = false;
+    if (!side_ok) (void)hipGetLastError();
+    hipStream_t main_stream = ctx->stream;
+    if (sort_source && side_ok) {
+        ICP_HIP_CHECK(hipEventRecord(ctx->side_ev, main_stream));      // whatever produced src is queued on the main stream
+        ICP_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));
+        ctx->stream = ctx->side;
+        const int rc = grid_build(ctx, src, n, dim, qsort, 1);
+        ctx->stream = main_stream;
+        if (rc) return rc;
+    }
+    if (int rc = grid_build(ctx, tgt, m, dim, grid)) return rc;
+    if (sort_source && side_ok) {
+        ICP_HIP_CHECK(hipEventRecord(ctx->side_ev, ctx->side));
+        ICP_HIP_CHECK(hipStreamWaitEvent(main_stream, ctx->side_ev, 0));
+    } else if (sort_source && grid.usable) {
+        if (int rc = grid_build(ctx, src, n, dim, qsort, 1)) return rc;
+    }
+    return ICP_OK;
+}
+}  // namespace icp
+
 extern "C" int icp_rigid_run(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
                              double tol, int max_iter, int use_tol, unsigned flags, double *T_out_dev,
                              double *err_hist_dev, int32_t *iters_out_dev, int32_t *idx_out) {
@@ -719,22 +753,18 @@ extern "C" int icp_rigid_run(icp_ctx *ctx, const double *src, int64_t n, const d
     ICP_REQUIRE(max_iter > 0, "run = 0 leaves R undefined (icp_3d.py:118-120)");
     if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
     if (int rc = ensure(ctx, ctx->work_c, (size_t)n * dim * sizeof(double))) return rc;
-    // the target never changes inside the loop: build its search grid once
-    GridBuild grid, qsort;
-    if (grid_worthwhile(n, m, flags))
-        if (int rc = grid_build(ctx, tgt, m, dim, grid)) return rc;
-    if (!grid.usable) flags |= ICP_FORCE_BRUTE;
+    // the target never changes inside the loop: build its search grid once.
     // With the grid, put the source into Morton order once: lanes of a wave then search the same
     // few cells, and a rigid motion keeps neighbours neighbours, so the order stays good for
     // every iteration.  Reductions run over the sorted copy (any order is a valid sum order);
     // only the user-visible correspondences are scattered back to the caller's order.
+    GridBuild grid, qsort;
     const int32_t *order = nullptr;
-    if (grid.usable && n >= 32768) {
-        if (int rc = grid_build(ctx, src, n, dim, qsort, 1)) return rc;
-        if (qsort.usable) {
-            src = qsort.spts;
-            order = qsort.sidx;
-        }
+    if (int rc = build_grids(ctx, src, n, tgt, m, dim, flags, grid, qsort)) return rc;
+    if (!grid.usable) flags |= ICP_FORCE_BRUTE;
+    if (grid.usable && qsort.usable) {
+        src = qsort.spts;
+        order = qsort.sidx;
     }
     int32_t *idx = idx_out;
     if (!idx || order) {
@@ -883,16 +913,12 @@ extern "C" int icp_rigid_run_dist(icp_ctx *ctx, const double *src, int64_t n, co
     if (int rc = ensure(ctx, ctx->work_c, (size_t)n * dim * sizeof(double))) return rc;
     if (int rc = ensure(ctx, ctx->work_d, (size_t)n * sizeof(int32_t) * 2)) return rc;
     GridBuild grid, qsort;
-    if (grid_worthwhile(n, m, flags))
-        if (int rc = grid_build(ctx, tgt, m, dim, grid)) return rc;
-    if (!grid.usable) flags |= ICP_FORCE_BRUTE;
     const int32_t *order = nullptr;
-    if (grid.usable && n >= 32768) {
-        if (int rc = grid_build(ctx, src, n, dim, qsort, 1)) return rc;
-        if (qsort.usable) {
-            src = qsort.spts;
-            order = qsort.sidx;
-        }
+    if (int rc = build_grids(ctx, src, n, tgt, m, dim, flags, grid, qsort)) return rc;
+    if (!grid.usable) flags |= ICP_FORCE_BRUTE;
+    if (grid.usable && qsort.usable) {
+        src = qsort.spts;
+        order = qsort.sidx;
     }
     RigidState *st = (RigidState *)ctx->small.ptr;
     // a single rank needs no buffer from the caller: the 17 doubles live behind the RigidState block
