@@ -229,22 +229,24 @@ __global__ __launch_bounds__(1024) void occupancy_kernel(const double *__restric
         }
     // one walk over the (at most 32) predecessors of every sample serves all levels: two codes share a level-l cell iff
     // they agree above dim*l bits, i.e. from level ceil(bitlength(a ^ b) / dim) upwards
-    unsigned int cnt[14];
-#pragma unroll
-    for (int l = 0; l < 14; ++l) cnt[l] = 0u;
+    // (per thread at most 4 x 32 pairs: the counts per first-shared level fit 8-bit fields of two 64-bit words; the
+    //  block runs on ONE compute unit, so the instructions of this walk are its run time)
+    unsigned long long h0 = 0ull, h1 = 0ull;
     for (int i = threadIdx.x; i < ns; i += blockDim.x) {
         const uint32_t ci = code[i];
         for (int d = 1; d <= 32 && i - d >= 0; ++d) {
             const uint32_t x = ci ^ code[i - d];
             const int nb = x ? 32 - __clz((int)x) : 0;
-            const int lmin = (nb + dim - 1) / dim;
-#pragma unroll
-            for (int l = 0; l < 14; ++l) cnt[l] += l >= lmin ? 1u : 0u;
+            const int lmin = dim == 3 ? (nb + 2) / 3 : (nb + 1) >> 1;
+            if (lmin < 8) h0 += 1ull << (8 * lmin);
+            else h1 += 1ull << (8 * (lmin - 8));
         }
     }
+    unsigned int run = 0u;  // pairs[l] = pairs whose first shared level is <= l
 #pragma unroll
     for (int l = 0; l < 14; ++l) {
-        unsigned int v = cnt[l];
+        run += (unsigned int)(((l < 8 ? h0 : h1) >> (8 * (l & 7))) & 0xffull);
+        unsigned int v = run;
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(&pairs[l], v);
     }
