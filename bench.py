@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--no-nicp", action="store_true", help="skip extra.nicp_c3 (about 20 s)")
     ap.add_argument("--no-check", action="store_true", help="skip the brute-force check of the timed run's correspondences")
     ap.add_argument("--brute", action="store_true", help="force the brute-force closest-point kernel")
+    ap.add_argument("--no-fuse", action="store_true", help="ICP_NO_FUSE: moved source as an array, apply / error as kernels of their own")
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="one process, one GPU: run the SHARDED entry point with a one-rank RCCL group and make the library "
                          "call back every collective (measures the host cost of the multi-GPU path on one GPU)")
@@ -214,8 +215,10 @@ def main():
     def run(steps, want_idx=True):
         """ONE library call = `steps` whole ICP iterations, device-resident, set-up included."""
         if distributed or comm is not None:
-            return rigid_icp_dist(src_d, tgt_d, 0.0, steps, use_tol=False, force_brute=args.brute, want_idx=want_idx, comm=comm, ctx=ctx)
-        return rigid.rigid_icp(src_d, tgt_d, 0.0, steps, use_tol=False, force_brute=args.brute, want_idx=want_idx, ctx=ctx)
+            return rigid_icp_dist(src_d, tgt_d, 0.0, steps, use_tol=False, force_brute=args.brute, want_idx=want_idx, comm=comm, ctx=ctx,
+                                  no_fuse=args.no_fuse)
+        return rigid.rigid_icp(src_d, tgt_d, 0.0, steps, use_tol=False, force_brute=args.brute, want_idx=want_idx, ctx=ctx,
+                               no_fuse=args.no_fuse)
 
     def timed(steps):
         barrier()

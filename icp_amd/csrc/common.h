@@ -54,6 +54,7 @@ struct icp_ctx {
     icp::Scratch sort_a, sort_b, sort_c, sort_d;          // Morton order of the queries
     icp::Scratch sort_tmp;                                // temporary storage of the stable code sort (stablesort.hip)
     icp::Scratch defer;                                   // grid search: queries handed to the wave-per-query pass
+    icp::Scratch err_part;                                // fused rigid loop: per-block error sums of a search
     void *defer_cleared = nullptr;                        // buffer whose two counters are known to be in step
     int defer_parity = 0;                                 // which of the two counters the next search uses
     // nicp_solve replays its CG iterations as a hipGraph; graphs cannot be captured on the legacy
@@ -96,9 +97,17 @@ int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &g
 // same, into caller-owned scratch (persistent target handles)
 int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, Scratch &sa, Scratch &sb,
                     Scratch &sc, Scratch &sd, bool stable = false);
+// Fused rigid loop: the queries are src . R + t (R, t: device memory, read by the search kernels themselves) and the
+// search also sums the distances to the hints = the previous iteration's error (grid.hip, grid_query_kernel<FUSED>).
+// Out: where the per-block error sums are and how many there are (context scratch, valid until the next search).
+struct FusedApply {
+    const double *R, *t;
+    double **err_part;
+    int *n_err;
+};
 int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
                const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done, const int32_t *hint = nullptr,
-               bool pos_mode = false);
+               bool pos_mode = false, const FusedApply *fa = nullptr);
 // internal flag of closest_dispatch: correspondences (and hints) are SORTED POSITIONS into GridBuild::spts /
 // sidx instead of original indices (icp_rigid_run keeps them that way between iterations: the gathers of the
 // reduction kernels then walk the Morton-sorted copy almost sequentially)
@@ -107,7 +116,7 @@ constexpr unsigned ICP_INTERNAL_POS = 0x10000u;
 // correspondence buffers)
 int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
                      unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done,
-                     const GridBuild *grid = nullptr, const int32_t *hint_from = nullptr);
+                     const GridBuild *grid = nullptr, const int32_t *hint_from = nullptr, const FusedApply *fa = nullptr);
 bool grid_worthwhile(int64_t n, int64_t m, unsigned flags);
 // exact k nearest (k = 6 or 8) by the key fl(sqrt(d2)), ties to the lower index, through a built grid
 int grid_knn(icp_ctx *ctx, const GridBuild &gb, const double *q, int64_t nq, int k, int32_t *idx_out, double *dist_out);

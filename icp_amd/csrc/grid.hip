@@ -399,7 +399,11 @@ struct Deferred {
     double best;
 };
 
-template <int DIM, bool LE, int QB, int WPE>
+// FUSED (the rigid loop from its second iteration on, kabsch.hip): the query is src[q] moved by the transform the last
+// solve left in device memory (the arithmetic of apply_err_kernel, so the same bits as a materialised copy), and the
+// distance to its hint -- last iteration's correspondence -- is that iteration's error term (icp_3d.py:113-114):
+// the block's sum of them goes to err_part[block], which saves the loop a streaming kernel and a reduction launch.
+template <int DIM, bool LE, int QB, int WPE, bool FUSED = false>
 __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void grid_query_kernel(const double *__restrict__ src, int64_t n,
                                                        const int32_t *__restrict__ qorder,
                                                        const double4 *__restrict__ recs,
@@ -409,7 +413,9 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                                                        long long *__restrict__ dbg, int cap,
                                                        Deferred *__restrict__ deferred, uint32_t *__restrict__ n_deferred,
                                                        const int32_t *hint, const uint32_t *__restrict__ inv, uint32_t m,
-                                                       int pos_mode, int xcd_chunk) {
+                                                       int pos_mode, int xcd_chunk, const double *__restrict__ Rm = nullptr,
+                                                       const double *__restrict__ tv = nullptr,
+                                                       double *__restrict__ err_part = nullptr) {
     if (done && *done) return;
     // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), each
     // with its own 4 MiB L2, and the queries arrive in Morton order.  The launch is cut into super-chunks of
@@ -422,13 +428,26 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         blk = (int64_t)sc * per + (int64_t)(r & 7u) * xcd_chunk + (r >> 3);
     }
     const int64_t t = blk * QB + threadIdx.x;
-    if (t >= n) return;
+    if (!FUSED && t >= n) return;
+    const bool in_range = t < n;     // FUSED: every thread stays until the block's error sum is formed
     const long long t_begin = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
     int dbg_levels = 0, dbg_cand = 0;
-    const int64_t q = qorder ? (int64_t)qorder[t] : t;
+    const int64_t q = in_range ? (qorder ? (int64_t)qorder[t] : t) : 0;
     double s[DIM];
 #pragma unroll
     for (int a = 0; a < DIM; ++a) s[a] = src[q * DIM + a];
+    if (FUSED) {   // ss = src R + t, operation for operation as apply_err_kernel forms it
+        double o[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            double v = s[0] * Rm[c];
+#pragma unroll
+            for (int k = 1; k < DIM; ++k) v += s[k] * Rm[k * DIM + c];
+            o[c] = v + tv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) s[c] = o[c];
+    }
     int c0[DIM];
     cell_of<DIM>(s, gp, c0);
     double slack_abs[DIM];
@@ -448,6 +467,32 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         for (int a = 0; a < DIM; ++a) {
             finite = finite && fabs(s[a]) < __builtin_inf();
             isnan = isnan || s[a] != s[a];
+        }
+        if (FUSED) {
+            // error term of the previous iteration: ||nn - ss|| with nn the hinted record (d2 summed as apply_err_kernel
+            // sums it: ((0 + dx^2) + dy^2) + dz^2); a non-finite query contributes its NaN / inf like there
+            double e = 0.0;
+            if (in_range) {
+                const double4 rc = recs[(uint32_t)hint[q]];
+                const double dx = rc.x - s[0], dy = rc.y - s[1];
+                double d = dx * dx + dy * dy;
+                if (DIM == 3) {
+                    const double dz = rc.z - s[2];
+                    d = d + dz * dz;
+                }
+                e = sqrt(d);
+            }
+            __shared__ double ered[QB / 64];
+            const double w = wave_sum(e);
+            if ((threadIdx.x & 63) == 0) ered[threadIdx.x >> 6] = w;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double v = ered[0];
+#pragma unroll
+                for (int k = 1; k < QB / 64; ++k) v += ered[k];
+                err_part[blk] = v;
+            }
+            if (!in_range) return;
         }
         if (!finite) {
             idx_out[q] = pos_mode ? (int32_t)inv[0] : 0;
@@ -688,7 +733,8 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double *__restrict
                                                         const Deferred *__restrict__ deferred,
                                                         const uint32_t *__restrict__ n_deferred,
                                                         uint32_t *__restrict__ next_counter,
-                                                        const uint32_t *__restrict__ inv, int pos_mode) {
+                                                        const uint32_t *__restrict__ inv, int pos_mode,
+                                                        const double *__restrict__ Rm, const double *__restrict__ tv) {
     // the two counters alternate between searches: nobody touches the other one during this search, so it is
     // cleared here for the next search (before the `done` test, so that it is clear whatever that says)
     if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0u;
@@ -704,6 +750,18 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double *__restrict
         double s[DIM];
 #pragma unroll
         for (int a = 0; a < DIM; ++a) s[a] = src[q * DIM + a];
+        if (Rm) {   // fused rigid loop: the same moved query as in the per-lane pass
+            double o[DIM];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                double v = s[0] * Rm[c];
+#pragma unroll
+                for (int k = 1; k < DIM; ++k) v += s[k] * Rm[k * DIM + c];
+                o[c] = v + tv[c];
+            }
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) s[c] = o[c];
+        }
         int c0[DIM];
         cell_of<DIM>(s, gp, c0);
         double best = dq.best;     // group-uniform between levels
@@ -1125,7 +1183,8 @@ long long *g_grid_dbg = nullptr;    // per-lane instrumentation (ICP_GRID_DEBUG 
 hipEvent_t *g_grid_events = nullptr;  // [3]: before the per-lane pass, between the passes, after the deferred pass
 
 int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
-               const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done, const int32_t *hint, bool pos_mode) {
+               const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done, const int32_t *hint, bool pos_mode,
+               const FusedApply *fa) {
     hipStream_t st = ctx->stream;
     // levels the per-lane pass handles itself (ICP_GRID_CAP=0: all of them, single pass)
     static const int cap_env = getenv("ICP_GRID_CAP") ? atoi(getenv("ICP_GRID_CAP")) : 1;
@@ -1164,25 +1223,40 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
         nb = (nb + per - 1) / per * per;            // blocks past the end return at once
     }
     unsigned nb2 = n < 8192 ? (unsigned)n : 8192u;   // one wave per deferred query, at most
-#define ICP_GQ(D, L) \
+    const double *fR = nullptr, *ft = nullptr;
+    if (fa) {   // fused rigid loop (FusedApply in common.h): needs positions as hints, the plain argmin and both passes
+        if (le || !hint || !pos_mode || qorder || d2_out || thr || cap >= 1000) {
+            set_error("grid_query: the fused form needs hints as sorted positions and the two-pass argmin search");
+            return ICP_ERR_ARG;
+        }
+        if (int rc = ensure(ctx, ctx->err_part, (size_t)nb * sizeof(double))) return rc;
+        fR = fa->R;
+        ft = fa->t;
+        *fa->err_part = (double *)ctx->err_part.ptr;
+        *fa->n_err = (int)nb;
+    }
+#define ICP_GQ(D, L, F) \
     do { \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[0], st); \
-        hipLaunchKernelGGL((grid_query_kernel<D, L, 256, 4>), dim3(nb), dim3(256), 0, st, src, n, qorder, (const double4 *)gb.recs, \
+        hipLaunchKernelGGL((grid_query_kernel<D, L, 256, 4, F>), dim3(nb), dim3(256), 0, st, src, n, qorder, (const double4 *)gb.recs, \
                            (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, g_grid_dbg, cap, dlist, ndef, hint, \
-                           (const uint32_t *)gb.inv, (uint32_t)gb.m, pos_mode ? 1 : 0, xcd_chunk); \
+                           (const uint32_t *)gb.inv, (uint32_t)gb.m, pos_mode ? 1 : 0, xcd_chunk, fR, ft, \
+                           fa ? (double *)ctx->err_part.ptr : (double *)nullptr); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[1], st); \
         if (cap < 1000) \
             hipLaunchKernelGGL((grid_defer_kernel<D, L>), dim3(nb2), dim3(64), 0, st, src, (const double4 *)gb.recs, \
                                (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (const Deferred *)dlist, \
-                               (const uint32_t *)ndef, ndef_next, (const uint32_t *)gb.inv, pos_mode ? 1 : 0); \
+                               (const uint32_t *)ndef, ndef_next, (const uint32_t *)gb.inv, pos_mode ? 1 : 0, fR, ft); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
     } while (0)
     if (gb.gp.dim == 3) {
-        if (le) ICP_GQ(3, true);
-        else ICP_GQ(3, false);
+        if (le) ICP_GQ(3, true, false);
+        else if (fa) ICP_GQ(3, false, true);
+        else ICP_GQ(3, false, false);
     } else {
-        if (le) ICP_GQ(2, true);
-        else ICP_GQ(2, false);
+        if (le) ICP_GQ(2, true, false);
+        else if (fa) ICP_GQ(2, false, true);
+        else ICP_GQ(2, false, false);
     }
 #undef ICP_GQ
     ICP_HIP_CHECK(hipGetLastError());

@@ -337,28 +337,6 @@ __global__ void kabsch_solve_kernel(const double *__restrict__ sums, const doubl
     kabsch_from_sums<DIM>(sums, cs, ct, R_out, t_out);
 }
 
-// fused single-GPU form: final reduction of the block partials + solve in one launch
-template <int DIM>
-__global__ __launch_bounds__(RB) void reduce_solve_kernel(const double *__restrict__ partial, int nb,
-                                                          const double *__restrict__ cs, const double *__restrict__ ct,
-                                                          double *__restrict__ sums_out, double *__restrict__ R_out,
-                                                          double *__restrict__ t_out, const int32_t *__restrict__ done) {
-    if (done && *done) return;
-    __shared__ double tot[kSumSlots];
-    // the shifts are fetched before the sums they are combined with (one memory round trip less on the serial tail)
-    double csr[DIM], ctr[DIM];
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            csr[c] = cs[c];
-            ctr[c] = ct[c];
-        }
-    }
-    block_reduce_partials(partial, nb, tot);
-    if (threadIdx.x < kSumSlots) sums_out[threadIdx.x] = tot[threadIdx.x];
-    if (threadIdx.x == 0) kabsch_from_sums<DIM>(tot, csr, ctr, R_out, t_out);
-}
-
 template <int DIM>
 __device__ void kabsch_from_sums(const double *sums, const double *__restrict__ cs, const double *__restrict__ ct,
                                  double *__restrict__ R_out, double *__restrict__ t_out) {
@@ -459,30 +437,6 @@ __global__ void rigid_init_kernel(RigidState *st) {
     st->err_prev = 100000000.0;
     st->done = 0;
     st->iters = 0;
-}
-
-// final reduction of the error partials + the end-of-iteration bookkeeping (icp_3d.py:107,114-117)
-__global__ __launch_bounds__(RB) void reduce_step_kernel(const double *__restrict__ partial, int nb, RigidState *st,
-                                                         double tol, int use_tol, double *err_hist) {
-    if (st->done) return;
-    __shared__ double red[RB];
-    const int tid = threadIdx.x;
-    double v = 0.0;
-    for (int b = tid; b < nb; b += RB) v += partial[(int64_t)b * kSumSlots];
-    red[tid] = v;
-    __syncthreads();
-    for (int o = RB / 2; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const double e = st->err_prev, err = red[0];
-        st->err = err;
-        st->err_prev = err;
-        if (err_hist) err_hist[st->iters] = err;
-        st->iters += 1;
-        if (use_tol && (e - err) < tol) st->done = 1;
-    }
 }
 
 // icp_3d.py:118-121
@@ -744,71 +698,6 @@ static int build_grids(icp_ctx *ctx, const double *src, int64_t n, const double 
 }
 }  // namespace icp
 
-extern "C" int icp_rigid_run(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
-                             double tol, int max_iter, int use_tol, unsigned flags, double *T_out_dev,
-                             double *err_hist_dev, int32_t *iters_out_dev, int32_t *idx_out) {
-    ICP_COMMON_ARGS(ctx, dim);
-    ICP_REQUIRE(src && tgt && T_out_dev, "null pointer");
-    ICP_REQUIRE(n > 0 && m > 0 && m < 0x7fffffff, "need n > 0 and 0 < m < 2^31");
-    ICP_REQUIRE(max_iter > 0, "run = 0 leaves R undefined (icp_3d.py:118-120)");
-    if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
-    if (int rc = ensure(ctx, ctx->work_c, (size_t)n * dim * sizeof(double))) return rc;
-    // the target never changes inside the loop: build its search grid once.
-    // With the grid, put the source into Morton order once: lanes of a wave then search the same
-    // few cells, and a rigid motion keeps neighbours neighbours, so the order stays good for
-    // every iteration.  Reductions run over the sorted copy (any order is a valid sum order);
-    // only the user-visible correspondences are scattered back to the caller's order.
-    GridBuild grid, qsort;
-    const int32_t *order = nullptr;
-    if (int rc = build_grids(ctx, src, n, tgt, m, dim, flags, grid, qsort)) return rc;
-    if (!grid.usable) flags |= ICP_FORCE_BRUTE;
-    if (grid.usable && qsort.usable) {
-        src = qsort.spts;
-        order = qsort.sidx;
-    }
-    int32_t *idx = idx_out;
-    if (!idx || order) {
-        if (int rc = ensure(ctx, ctx->work_d, (size_t)n * sizeof(int32_t))) return rc;
-        idx = (int32_t *)ctx->work_d.ptr;
-    }
-    RigidState *st = (RigidState *)ctx->small.ptr;
-    double *ss = (double *)ctx->work_c.ptr;
-    hipStream_t s = ctx->stream;
-    hipLaunchKernelGGL(rigid_init_kernel, dim3(1), dim3(1), 0, s, st);
-    ICP_HIP_CHECK(hipGetLastError());
-    // iteration-invariant shifts: mean of the ORIGINAL source (Q1) and of the target
-    if (int rc = column_sums(ctx, src, n, dim, st->cs, 1)) return rc;
-    if (int rc = column_sums(ctx, tgt, m, dim, st->ct, 1)) return rc;
-    ICP_HIP_CHECK(hipMemcpyAsync(ss, src, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToDevice, s));  // icp_3d.py:104
-    const int32_t *done = &st->done;
-    // With the grid, correspondences stay SORTED TARGET POSITIONS inside the loop: the reductions then
-    // gather from the Morton-sorted copy of the target (queries are in Morton order too, so neighbouring
-    // lanes read neighbouring records) and last iteration's position is the next search's hint directly.
-    const bool pos = grid.usable && !(flags & ICP_FORCE_BRUTE);
-    const double *tgt_rows = pos ? grid.spts : tgt;
-    flags = (flags & ~(unsigned)ICP_HINT_IDX) | (pos ? ICP_INTERNAL_POS : 0u);
-    for (int it = 0; it < max_iter; ++it) {
-        // from the second iteration on, idx holds the previous correspondences: a tight starting bound
-        if (int rc = closest_dispatch(ctx, ss, n, tgt, m, dim, it > 0 ? (flags | ICP_HINT_IDX) : flags, idx, nullptr, done, &grid))
-            return rc;
-        int nb = 0;
-        const double *part = (const double *)ctx->partials.ptr;
-        if (int rc = shard_sums(ctx, src, tgt_rows, idx, n, dim, st->cs, st->ct, st->sums, done, &nb)) return rc;
-        part = (const double *)ctx->partials.ptr;
-        if (dim == 3) hipLaunchKernelGGL(reduce_solve_kernel<3>, dim3(1), dim3(RB), 0, s, part, nb, (const double *)st->cs, (const double *)st->ct, st->sums, st->R, st->t, done);
-        else hipLaunchKernelGGL(reduce_solve_kernel<2>, dim3(1), dim3(RB), 0, s, part, nb, (const double *)st->cs, (const double *)st->ct, st->sums, st->R, st->t, done);
-        if (int rc = apply_err(ctx, 1, src, tgt_rows, idx, n, dim, st->R, st->t, ss, st->sums, done, &nb)) return rc;
-        hipLaunchKernelGGL(reduce_step_kernel, dim3(1), dim3(RB), 0, s, part, nb, st, tol, use_tol, err_hist_dev);
-        ICP_HIP_CHECK(hipGetLastError());
-    }
-    if (idx_out && (order || pos))
-        hipLaunchKernelGGL(unsort_idx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int32_t *)idx, order,
-                           pos ? (const int32_t *)grid.sidx : (const int32_t *)nullptr, n, idx_out);
-    hipLaunchKernelGGL(rigid_finish_kernel, dim3(1), dim3(1), 0, s, (const RigidState *)st, dim, T_out_dev, iters_out_dev);
-    ICP_HIP_CHECK(hipGetLastError());
-    return ICP_OK;
-}
-
 // ---------------------------------------------------------------- source-sharded loop
 // One rank's share of icp_3d.py:102-121 with the source rows split over ranks and the target replicated.  Per
 // iteration ONE all-reduce of 17 doubles: the 16 shifted sums of this iteration and the error of the previous one,
@@ -828,14 +717,70 @@ __global__ __launch_bounds__(RB) void dist_pack_means_kernel(const double *__res
 __global__ void dist_means_kernel(const double *__restrict__ buf, int dim, RigidState *st) {
     if (threadIdx.x < dim) st->cs[threadIdx.x] = buf[threadIdx.x] / buf[3];  // np.mean: sum / N (icp_3d.py:69)
 }
-// buf[0..15] = this rank's sums of iteration `it`, buf[16] = its error of iteration it - 1
+// sum of the per-block error sums a fused search left (fixed tree: deterministic); valid in thread 0
+__device__ __forceinline__ double block_sum_err(const double *__restrict__ err_part, int nerr, double *red) {
+    const int tid = threadIdx.x;
+    double v = 0.0;
+    for (int b = tid; b < nerr; b += RB) v += err_part[b];
+    red[tid] = v;
+    __syncthreads();
+    for (int o = RB / 2; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    return red[0];
+}
+
+// buf[0..15] = this rank's sums of iteration `it`, buf[16] = its error of iteration it - 1 (st->err, or -- fused
+// loop -- the sum of the error partials the search of iteration `it` formed on the way)
 __global__ __launch_bounds__(RB) void dist_pack_kernel(const double *__restrict__ partial, int nb, const RigidState *st,
-                                                       int first, double *__restrict__ buf) {
+                                                       int first, double *__restrict__ buf,
+                                                       const double *__restrict__ err_part, int nerr) {
     __shared__ double tot[kSumSlots];
+    __shared__ double red[RB];
     const int done = st->done;
     if (!done) block_reduce_partials(partial, nb, tot);
+    double err = 0.0;
+    if (!done && !first) err = err_part ? block_sum_err(err_part, nerr, red) : st->err;
     if (threadIdx.x < kSumSlots) buf[threadIdx.x] = done ? 0.0 : tot[threadIdx.x];
-    if (threadIdx.x == kSumSlots) buf[kSumSlots] = (done || first) ? 0.0 : st->err;
+    if (threadIdx.x == 0) buf[kSumSlots] = err;
+}
+
+// One rank, fused loop: the reduction of the sums, the error of the previous iteration with its bookkeeping
+// (icp_3d.py:114-117) and the solve of this one in a single launch.
+template <int DIM>
+__global__ __launch_bounds__(RB) void fused_solve_kernel(const double *__restrict__ partial, int nb,
+                                                         const double *__restrict__ err_part, int nerr, RigidState *st,
+                                                         int first, double tol, int use_tol, double *__restrict__ err_hist) {
+    if (st->done) return;
+    __shared__ double tot[kSumSlots];
+    __shared__ double red[RB];
+    double csr[DIM], ctr[DIM], e_prev = 0.0;
+    int iters = 0;
+    if (threadIdx.x == 0) {   // fetched before the sums they are combined with
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            csr[c] = st->cs[c];
+            ctr[c] = st->ct[c];
+        }
+        e_prev = st->err_prev;
+        iters = st->iters;
+    }
+    const double err = first ? 0.0 : block_sum_err(err_part, nerr, red);
+    block_reduce_partials(partial, nb, tot);
+    if (threadIdx.x != 0) return;
+    if (!first) {
+        st->err = err;
+        st->err_prev = err;
+        if (err_hist) err_hist[iters] = err;
+        st->iters = iters + 1;
+        if (use_tol && (e_prev - err) < tol) {
+            st->done = 1;    // R, t stay those of the last executed iteration
+            return;
+        }
+    }
+    for (int k = 0; k < kSumSlots; ++k) st->sums[k] = tot[k];
+    kabsch_from_sums<DIM>(tot, csr, ctr, st->R, st->t);
 }
 // after the all-reduce: end-of-iteration bookkeeping of iteration it - 1 (icp_3d.py:114-117), then the solve of `it`
 template <int DIM>
@@ -899,19 +844,24 @@ static int comm_allreduce(const icp_comm *cm, int count) {
 
 }  // namespace icp
 
-extern "C" int icp_rigid_run_dist(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim, double tol,
-                                  int max_iter, int use_tol, unsigned flags, double *T_out_dev, double *err_hist_dev,
-                                  int32_t *iters_out_dev, int32_t *idx_out, const icp_comm *comm) {
-    ICP_COMMON_ARGS(ctx, dim);
-    ICP_REQUIRE(src && tgt && T_out_dev && comm, "null pointer");
-    ICP_REQUIRE(n > 0 && m > 0 && m < 0x7fffffff, "need n > 0 (every rank holds rows) and 0 < m < 2^31");
-    ICP_REQUIRE(max_iter > 0, "run = 0 leaves R undefined (icp_3d.py:118-120)");
-    ICP_REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, "bad rank / world");
-    ICP_REQUIRE(comm->world == 1 || (comm->reduce_buf_dev && comm->allreduce_sum), "comm buffer / callback missing");
+namespace icp {
+// icp_rigid_run (comm = null) and icp_rigid_run_dist.  Per iteration: search -> the shard's 16 sums -> [all-reduce] ->
+// solve -> error; the error of iteration k is only needed by the stop test at the end of k, so it is reduced together
+// with the sums of k + 1 and the test runs one Match late (that Match goes into the other of two correspondence
+// buffers and is discarded).  Fused form (grid search, plain comparison; ICP_NO_FUSE keeps the other): the moved source
+// is never written -- the search kernels apply R, t to the original rows themselves and add up the distances to their
+// hints, which ARE the previous iteration's error terms -- so an iteration is search (2 launches) + sums + solve.
+static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim, double tol,
+                      int max_iter, int use_tol, unsigned flags, double *T_out_dev, double *err_hist_dev,
+                      int32_t *iters_out_dev, int32_t *idx_out, const icp_comm *comm) {
+    const int world = comm ? comm->world : 1;
     if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
     if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
-    if (int rc = ensure(ctx, ctx->work_c, (size_t)n * dim * sizeof(double))) return rc;
     if (int rc = ensure(ctx, ctx->work_d, (size_t)n * sizeof(int32_t) * 2)) return rc;
+    // the target never changes inside the loop: build its search grid once.  With the grid, put the source into
+    // Morton order once: lanes of a wave then search the same few cells, and a rigid motion keeps neighbours
+    // neighbours, so the order stays good for every iteration.  Reductions run over the sorted copy (any order is a
+    // valid sum order); only the user-visible correspondences are scattered back to the caller's order.
     GridBuild grid, qsort;
     const int32_t *order = nullptr;
     if (int rc = build_grids(ctx, src, n, tgt, m, dim, flags, grid, qsort)) return rc;
@@ -920,15 +870,27 @@ extern "C" int icp_rigid_run_dist(icp_ctx *ctx, const double *src, int64_t n, co
         src = qsort.spts;
         order = qsort.sidx;
     }
+    // With the grid, correspondences stay SORTED TARGET POSITIONS inside the loop: the reductions then gather from the
+    // Morton-sorted copy of the target (queries are in Morton order too, so neighbouring lanes read neighbouring
+    // records) and last iteration's position is the next search's hint directly.
+    const bool pos = grid.usable && !(flags & ICP_FORCE_BRUTE);
+    const bool fused = pos && !(flags & (ICP_COMPARE_SQRT | ICP_NO_FUSE));
+    double *ss = nullptr;
+    if (!fused) {
+        if (int rc = ensure(ctx, ctx->work_c, (size_t)n * dim * sizeof(double))) return rc;
+        ss = (double *)ctx->work_c.ptr;
+    } else if (int rc = ensure(ctx, ctx->err_part, (size_t)(2 * ((n + 255) / 256) + 16) * sizeof(double))) {
+        return rc;   // (an upper bound of the search's padded block count: no reallocation inside the loop)
+    }
     RigidState *st = (RigidState *)ctx->small.ptr;
     // a single rank needs no buffer from the caller: the 17 doubles live behind the RigidState block
-    double *buf = comm->world > 1 ? comm->reduce_buf_dev : (double *)ctx->small.ptr + 128;
+    double *buf = world > 1 ? comm->reduce_buf_dev : (double *)ctx->small.ptr + 128;
     static_assert(sizeof(RigidState) <= 128 * sizeof(double), "RigidState overlaps the local reduce buffer");
-    double *ss = (double *)ctx->work_c.ptr, *part = (double *)ctx->partials.ptr;
+    double *part = (double *)ctx->partials.ptr;
     int32_t *ib[2] = {(int32_t *)ctx->work_d.ptr, (int32_t *)ctx->work_d.ptr + n};
     hipStream_t s = ctx->stream;
     hipLaunchKernelGGL(rigid_init_kernel, dim3(1), dim3(1), 0, s, st);
-    // global mean of the ORIGINAL source (Q1) from all-reduced column sums; the target is replicated, its mean is local
+    // global mean of the ORIGINAL source (Q1) from (all-reduced) column sums; the target is replicated, its mean is local
     {
         const int nb = nblocks_for(n);
         if (dim == 3) hipLaunchKernelGGL(column_sums_kernel<3>, dim3(nb), dim3(RB), 0, s, src, n, part);
@@ -939,26 +901,38 @@ extern "C" int icp_rigid_run_dist(icp_ctx *ctx, const double *src, int64_t n, co
         hipLaunchKernelGGL(dist_means_kernel, dim3(1), dim3(64), 0, s, (const double *)buf, dim, st);
     }
     if (int rc = column_sums(ctx, tgt, m, dim, st->ct, 1)) return rc;
-    ICP_HIP_CHECK(hipMemcpyAsync(ss, src, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToDevice, s));  // icp_3d.py:104
+    if (ss) ICP_HIP_CHECK(hipMemcpyAsync(ss, src, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToDevice, s));  // icp_3d.py:104
     const int32_t *done = &st->done;
-    const bool pos = grid.usable && !(flags & ICP_FORCE_BRUTE);
     const double *tgt_rows = pos ? grid.spts : tgt;
-    flags = (flags & ~(unsigned)ICP_HINT_IDX) | (pos ? ICP_INTERNAL_POS : 0u);
+    flags = (flags & ~(unsigned)(ICP_HINT_IDX | ICP_NO_FUSE)) | (pos ? ICP_INTERNAL_POS : 0u);
     for (int it = 0; it < max_iter; ++it) {
         int32_t *idx = ib[it & 1];
-        if (int rc = closest_dispatch(ctx, ss, n, tgt, m, dim, it > 0 ? (flags | ICP_HINT_IDX) : flags, idx, nullptr, done, &grid,
-                                      it > 0 ? ib[(it - 1) & 1] : nullptr))
+        const int first = it == 0 ? 1 : 0;
+        // from the second iteration on the previous correspondences are a tight starting bound
+        double *err_part = nullptr;
+        int nerr = 0;
+        const FusedApply fa = {st->R, st->t, &err_part, &nerr};
+        if (int rc = closest_dispatch(ctx, fused ? src : ss, n, tgt, m, dim, first ? flags : (flags | ICP_HINT_IDX), idx, nullptr,
+                                      done, &grid, first ? nullptr : ib[(it - 1) & 1], (fused && !first) ? &fa : nullptr))
             return rc;
         int nb = 0;
         if (int rc = shard_sums(ctx, src, tgt_rows, idx, n, dim, st->cs, st->ct, st->sums, done, &nb)) return rc;
-        hipLaunchKernelGGL(dist_pack_kernel, dim3(1), dim3(RB), 0, s, (const double *)part, nb, (const RigidState *)st, it == 0 ? 1 : 0, buf);
+        if (world == 1 && fused) {
+            if (dim == 3) hipLaunchKernelGGL(fused_solve_kernel<3>, dim3(1), dim3(RB), 0, s, (const double *)part, nb, (const double *)err_part, nerr, st, first, tol, use_tol, err_hist_dev);
+            else hipLaunchKernelGGL(fused_solve_kernel<2>, dim3(1), dim3(RB), 0, s, (const double *)part, nb, (const double *)err_part, nerr, st, first, tol, use_tol, err_hist_dev);
+        } else {
+            hipLaunchKernelGGL(dist_pack_kernel, dim3(1), dim3(RB), 0, s, (const double *)part, nb, (const RigidState *)st, first, buf, (const double *)err_part, nerr);
+            ICP_HIP_CHECK(hipGetLastError());
+            if (int rc = comm_allreduce(comm, kSumSlots + 1)) return rc;
+            if (dim == 3) hipLaunchKernelGGL(dist_solve_kernel<3>, dim3(1), dim3(64), 0, s, (const double *)buf, st, first, tol, use_tol, err_hist_dev);
+            else hipLaunchKernelGGL(dist_solve_kernel<2>, dim3(1), dim3(64), 0, s, (const double *)buf, st, first, tol, use_tol, err_hist_dev);
+        }
         ICP_HIP_CHECK(hipGetLastError());
-        if (int rc = comm_allreduce(comm, kSumSlots + 1)) return rc;
-        if (dim == 3) hipLaunchKernelGGL(dist_solve_kernel<3>, dim3(1), dim3(64), 0, s, (const double *)buf, st, it == 0 ? 1 : 0, tol, use_tol, err_hist_dev);
-        else hipLaunchKernelGGL(dist_solve_kernel<2>, dim3(1), dim3(64), 0, s, (const double *)buf, st, it == 0 ? 1 : 0, tol, use_tol, err_hist_dev);
-        if (int rc = apply_err(ctx, 1, src, tgt_rows, idx, n, dim, st->R, st->t, ss, st->sums, done, &nb)) return rc;
-        hipLaunchKernelGGL(dist_err_kernel, dim3(1), dim3(RB), 0, s, (const double *)part, nb, st);
-        ICP_HIP_CHECK(hipGetLastError());
+        if (!fused || it == max_iter - 1) {   // (fused: only the last iteration's error needs a pass of its own)
+            if (int rc = apply_err(ctx, 1, src, tgt_rows, idx, n, dim, st->R, st->t, ss, st->sums, done, &nb)) return rc;
+            hipLaunchKernelGGL(dist_err_kernel, dim3(1), dim3(RB), 0, s, (const double *)part, nb, st);
+            ICP_HIP_CHECK(hipGetLastError());
+        }
     }
     hipLaunchKernelGGL(dist_last_pack_kernel, dim3(1), dim3(1), 0, s, (const RigidState *)st, buf);
     ICP_HIP_CHECK(hipGetLastError());
@@ -971,6 +945,30 @@ extern "C" int icp_rigid_run_dist(icp_ctx *ctx, const double *src, int64_t n, co
     hipLaunchKernelGGL(rigid_finish_kernel, dim3(1), dim3(1), 0, s, (const RigidState *)st, dim, T_out_dev, iters_out_dev);
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
+}
+}  // namespace icp
+
+extern "C" int icp_rigid_run(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
+                             double tol, int max_iter, int use_tol, unsigned flags, double *T_out_dev,
+                             double *err_hist_dev, int32_t *iters_out_dev, int32_t *idx_out) {
+    ICP_COMMON_ARGS(ctx, dim);
+    ICP_REQUIRE(src && tgt && T_out_dev, "null pointer");
+    ICP_REQUIRE(n > 0 && m > 0 && m < 0x7fffffff, "need n > 0 and 0 < m < 2^31");
+    ICP_REQUIRE(max_iter > 0, "run = 0 leaves R undefined (icp_3d.py:118-120)");
+    return rigid_loop(ctx, src, n, tgt, m, dim, tol, max_iter, use_tol, flags, T_out_dev, err_hist_dev, iters_out_dev, idx_out,
+                      nullptr);
+}
+
+extern "C" int icp_rigid_run_dist(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim, double tol,
+                                  int max_iter, int use_tol, unsigned flags, double *T_out_dev, double *err_hist_dev,
+                                  int32_t *iters_out_dev, int32_t *idx_out, const icp_comm *comm) {
+    ICP_COMMON_ARGS(ctx, dim);
+    ICP_REQUIRE(src && tgt && T_out_dev && comm, "null pointer");
+    ICP_REQUIRE(n > 0 && m > 0 && m < 0x7fffffff, "need n > 0 (every rank holds rows) and 0 < m < 2^31");
+    ICP_REQUIRE(max_iter > 0, "run = 0 leaves R undefined (icp_3d.py:118-120)");
+    ICP_REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, "bad rank / world");
+    ICP_REQUIRE(comm->world == 1 || (comm->reduce_buf_dev && comm->allreduce_sum), "comm buffer / callback missing");
+    return rigid_loop(ctx, src, n, tgt, m, dim, tol, max_iter, use_tol, flags, T_out_dev, err_hist_dev, iters_out_dev, idx_out, comm);
 }
 
 extern "C" int icp_bench_grid_query(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,

@@ -51,9 +51,12 @@ enum {
     ICP_COMPARE_SQRT = 1u, /* nicp3d.cpp:56-63,142-164: compare rounded sqrt(d2) (Q12) */
     ICP_FORCE_BRUTE = 2u,  /* never use the spatial-grid search, always scan all targets */
     ICP_FORCE_GRID = 4u,   /* use the grid search whatever the problem size (tests) */
-    ICP_HINT_IDX = 8u      /* idx_out holds, on entry, some target index per query (typically the previous
+    ICP_HINT_IDX = 8u,     /* idx_out holds, on entry, some target index per query (typically the previous
                               iteration's correspondence): the grid search evaluates it first as its starting
                               bound.  The result is the same exact argmin; out-of-range entries are ignored. */
+    ICP_NO_FUSE = 16u      /* icp_rigid_run[_dist]: keep the moved source as an array and run `apply` and the error
+                              as kernels of their own instead of inside the grid search (same T and correspondences
+                              bit for bit, errors equal up to summation order; for tests and measurements) */
 };
 
 const char *icp_last_error(void);

@@ -232,3 +232,27 @@ def test_one_far_outlier_does_not_turn_the_grid_into_a_scan(rigid):
     t_brute = time.perf_counter() - t0
     assert torch.equal(gi, bi)
     assert t_grid * 20 < t_brute, (t_grid, t_brute)
+
+
+@pytest.mark.parametrize("dim,use_tol,n", [(3, True, 60000), (3, False, 45001), (2, True, 50000)])
+def test_fused_loop_equals_unfused_loop(rigid, dim, use_tol, n):
+    """From its second iteration on the loop never writes the moved source: the search kernels apply R, t to the
+    original rows themselves and add up the distances to their hints (= the previous iteration's error terms).
+    ICP_NO_FUSE keeps the moved source as an array and `apply` / the error as kernels of their own: the same
+    transform and correspondences bit for bit, the same number of iterations, errors equal up to summation order.
+    (n = 45001: a last block with one query.)"""
+    import torch
+    rng = np.random.default_rng(50 + dim)
+    tgt = rng.standard_normal((n + 7000, dim))
+    c, s = np.cos(0.15), np.sin(0.15)
+    R = np.eye(dim)
+    R[:2, :2] = [[c, s], [-s, c]]
+    src = ((tgt - 0.03) @ R)[rng.permutation(len(tgt))[:n]]
+    a = rigid.rigid_icp(src, tgt, 1e-3, 25, use_tol=use_tol, want_idx=True, force_grid=True)
+    b = rigid.rigid_icp(src, tgt, 1e-3, 25, use_tol=use_tol, want_idx=True, force_grid=True, no_fuse=True)
+    k = int(a["iters"].cpu()[0])
+    assert k == int(b["iters"].cpu()[0]) and (use_tol or k == 25)
+    assert torch.equal(a["T"], b["T"]) and torch.equal(a["idx"], b["idx"])
+    np.testing.assert_allclose(a["err_hist"].cpu().numpy()[:k], b["err_hist"].cpu().numpy()[:k], rtol=1e-13)
+    a2 = rigid.rigid_icp(src, tgt, 1e-3, 25, use_tol=use_tol, want_idx=True, force_grid=True)
+    assert torch.equal(a["err_hist"][:k], a2["err_hist"][:k])      # and reproducible bit for bit
