@@ -721,7 +721,15 @@ __global__ void dist_means_kernel(const double *__restrict__ buf, int dim, Rigid
 __device__ __forceinline__ double block_sum_err(const double *__restrict__ err_part, int nerr, double *red) {
     const int tid = threadIdx.x;
     double v = 0.0;
-    for (int b = tid; b < nerr; b += RB) v += err_part[b];
+    int b = tid;
+    for (; b + 7 * RB < nerr; b += 8 * RB) {   // loads of a batch issued before the first add (same order of additions)
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = err_part[b + u * RB];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += x[u];
+    }
+    for (; b < nerr; b += RB) v += err_part[b];
     red[tid] = v;
     __syncthreads();
     for (int o = RB / 2; o > 0; o >>= 1) {
