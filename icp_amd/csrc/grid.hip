@@ -403,7 +403,7 @@ struct Deferred {
 // solve left in device memory (the arithmetic of apply_err_kernel, so the same bits as a materialised copy), and the
 // distance to its hint -- last iteration's correspondence -- is that iteration's error term (icp_3d.py:113-114):
 // the block's sum of them goes to err_part[block], which saves the loop a streaming kernel and a reduction launch.
-template <int DIM, bool LE, int QB, int WPE, bool FUSED = false>
+template <int DIM, bool LE, int QB, int WPE, bool FUSED = false, int LISTN = 8, int UNRN = 4>
 __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void grid_query_kernel(const double *__restrict__ src, int64_t n,
                                                        const int32_t *__restrict__ qorder,
                                                        const double4 *__restrict__ recs,
@@ -473,7 +473,8 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             // sums it: ((0 + dx^2) + dy^2) + dz^2); a non-finite query contributes its NaN / inf like there
             double e = 0.0;
             if (in_range) {
-                const double4 rc = recs[(uint32_t)hint[q]];
+                const uint32_t h = (uint32_t)hint[q];
+                const double4 rc = recs[h < m ? h : 0u];   // (always in range inside the loop; never fault on a bad one)
                 const double dx = rc.x - s[0], dy = rc.y - s[1];
                 double d = dx * dx + dy * dy;
                 if (DIM == 3) {
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     // lockstep would cost (cells x longest range) trips per wave.  Instead each lane first lists
     // the ranges that survive its bound test, then all lanes walk their OWN concatenated list, so
     // a wave's trip count is the longest TOTAL, not the sum of per-cell maxima.
-    constexpr int LIST = 8;
+    constexpr int LIST = LISTN;
     __shared__ uint2 wl[LIST][QB];
     __shared__ float wlb[LIST][QB];  // lower bound of each listed cell (rounded down)
     const int lane_slot = threadIdx.x;
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 wl[k][lane_slot] = make_uint2(r0[k], r1[k]);
                 wlb[k][lane_slot] = fb[k];
             }
-            constexpr int UNR = 4;
+            constexpr int UNR = UNRN;
             int cur = 0;
             uint32_t p = 0, pe = 0;
             while (true) {
@@ -1235,10 +1236,10 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
         *fa->err_part = (double *)ctx->err_part.ptr;
         *fa->n_err = (int)nb;
     }
-#define ICP_GQ(D, L, F) \
+#define ICP_GQ2(D, L, F, LN, UN) \
     do { \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[0], st); \
-        hipLaunchKernelGGL((grid_query_kernel<D, L, 256, 4, F>), dim3(nb), dim3(256), 0, st, src, n, qorder, (const double4 *)gb.recs, \
+        hipLaunchKernelGGL((grid_query_kernel<D, L, 256, 4, F, LN, UN>), dim3(nb), dim3(256), 0, st, src, n, qorder, (const double4 *)gb.recs, \
                            (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, g_grid_dbg, cap, dlist, ndef, hint, \
                            (const uint32_t *)gb.inv, (uint32_t)gb.m, pos_mode ? 1 : 0, xcd_chunk, fR, ft, \
                            fa ? (double *)ctx->err_part.ptr : (double *)nullptr); \
@@ -1249,16 +1250,25 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
                                (const uint32_t *)ndef, ndef_next, (const uint32_t *)gb.inv, pos_mode ? 1 : 0, fR, ft); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
     } while (0)
+#define ICP_GQ(D, L, F) ICP_GQ2(D, L, F, 8, 4)
+    static const int list8 = getenv("ICP_GRID_LIST8") ? atoi(getenv("ICP_GRID_LIST8")) : 0;
+#define ICP_GQL(D, L, F) \
+    do { \
+        if (list8) ICP_GQ2(D, L, F, 8, 4); \
+        else ICP_GQ2(D, L, F, 4, 4); \
+    } while (0)
     if (gb.gp.dim == 3) {
-        if (le) ICP_GQ(3, true, false);
-        else if (fa) ICP_GQ(3, false, true);
-        else ICP_GQ(3, false, false);
+        if (le) ICP_GQL(3, true, false);
+        else if (fa) ICP_GQL(3, false, true);
+        else ICP_GQL(3, false, false);
     } else {
-        if (le) ICP_GQ(2, true, false);
-        else if (fa) ICP_GQ(2, false, true);
-        else ICP_GQ(2, false, false);
+        if (le) ICP_GQL(2, true, false);
+        else if (fa) ICP_GQL(2, false, true);
+        else ICP_GQL(2, false, false);
     }
+#undef ICP_GQL
 #undef ICP_GQ
+#undef ICP_GQ2
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
 }
