@@ -337,6 +337,11 @@ __global__ __launch_bounds__(GB) void scan_add_kernel(uint32_t *__restrict__ out
 
 // Gather into Morton order: sorted position `pos` holds point sidx[pos], the permutation of the stable code sort
 // (stablesort.hip: cells in code order, ascending index inside a cell -- the same order on every run).
+// Records readable past the last one (copies of it).  The per-lane search reads records in groups of UNR without
+// clamping to the end of a cell's range: what lies beyond is the next cell's records -- real targets, which any exact
+// search may look at -- and, at the very end of the array, these copies (same index, same distance: never preferred).
+constexpr int kRecPad = 7;
+
 template <int DIM>
 __global__ __launch_bounds__(GB) void scatter_kernel(const double *__restrict__ tgt, uint32_t *code,
                                                     int64_t m, double *__restrict__ spts, const int32_t *__restrict__ sidx,
@@ -352,6 +357,8 @@ __global__ __launch_bounds__(GB) void scatter_kernel(const double *__restrict__ 
     rec.z = DIM == 3 ? tgt[i * DIM + 2] : 0.0;
     rec.w = __longlong_as_double((long long)i);
     recs[pos] = rec;
+    if (pos == m - 1)   // kRecPad copies of the last record: the searches read whole groups of records past a range's end
+        for (int k = 1; k <= kRecPad; ++k) recs[pos + k] = rec;
 #pragma unroll
     for (int a = 0; a < DIM; ++a) spts[(int64_t)pos * DIM + a] = tgt[i * DIM + a];
     code[i] = (uint32_t)pos;  // the cell code is spent: the array becomes the inverse permutation (GridBuild::inv)
@@ -378,6 +385,8 @@ __global__ __launch_bounds__(GB) void scatter_atomic_kernel(const double *__rest
     rec.z = DIM == 3 ? tgt[i * DIM + 2] : 0.0;
     rec.w = __longlong_as_double((long long)i);
     recs[pos] = rec;
+    if ((int64_t)pos == m - 1)
+        for (int k = 1; k <= kRecPad; ++k) recs[pos + k] = rec;
     spts[(int64_t)pos * DIM] = rec.x;
     spts[(int64_t)pos * DIM + 1] = rec.y;
     if (DIM == 3) spts[(int64_t)pos * DIM + 2] = rec.z;
@@ -403,7 +412,7 @@ struct Deferred {
 // solve left in device memory (the arithmetic of apply_err_kernel, so the same bits as a materialised copy), and the
 // distance to its hint -- last iteration's correspondence -- is that iteration's error term (icp_3d.py:113-114):
 // the block's sum of them goes to err_part[block], which saves the loop a streaming kernel and a reduction launch.
-template <int DIM, bool LE, int QB, int WPE, bool FUSED = false, int LISTN = 8, int UNRN = 4>
+template <int DIM, bool LE, int QB, int WPE, bool FUSED = false, int LISTN = 4, int UNRN = 3>
 __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void grid_query_kernel(const double *__restrict__ src, int64_t n,
                                                        const int32_t *__restrict__ qorder,
                                                        const double4 *__restrict__ recs,
@@ -508,6 +517,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     // the ranges that survive its bound test, then all lanes walk their OWN concatenated list, so
     // a wave's trip count is the longest TOTAL, not the sum of per-cell maxima.
     constexpr int LIST = LISTN;
+    constexpr int SCANN = UNRN;   // records per trip, own-cell scan and list walk alike
     __shared__ uint2 wl[LIST][QB];
     __shared__ float wlb[LIST][QB];  // lower bound of each listed cell (rounded down)
     const int lane_slot = threadIdx.x;
@@ -534,12 +544,13 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         }
     };
     auto scan = [&](uint32_t p0, uint32_t p1) {
-        for (uint32_t p = p0; p < p1; p += 4) {
-            double4 rc[4];
+        for (uint32_t p = p0; p < p1; p += SCANN) {
+            double4 rc[SCANN];
+            const double4 *base = recs + p;   // no clamp at p1: see kRecPad
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rc[u] = recs[p + u < p1 ? p + u : p1 - 1];  // re-reads are idempotent
+            for (int u = 0; u < SCANN; ++u) rc[u] = base[u];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) eval(rc[u], p + u < p1 ? p + u : p1 - 1);
+            for (int u = 0; u < SCANN; ++u) eval(rc[u], p + u);
         }
     };
 
@@ -675,10 +686,12 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 if (__builtin_amdgcn_ballot_w64(work) == 0) break;
                 if (work) {
                     double4 rc[UNR];
+                    static_assert(UNR - 1 <= kRecPad, "records read past the end of the array");
+                    const double4 *base = recs + p;   // no clamp at pe: see kRecPad
 #pragma unroll
-                    for (int u = 0; u < UNR; ++u) rc[u] = recs[p + u < pe ? p + u : pe - 1];
+                    for (int u = 0; u < UNR; ++u) rc[u] = base[u];
 #pragma unroll
-                    for (int u = 0; u < UNR; ++u) eval(rc[u], p + u < pe ? p + u : pe - 1);
+                    for (int u = 0; u < UNR; ++u) eval(rc[u], p + u);
                     p += UNR;
                     dbg_cand += UNR;
                 }
@@ -1143,7 +1156,7 @@ int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBui
     gp.inv_h = 1.0 / gp.h;
     const int64_t ncell = 1ll << (dim * bits);
     const int64_t nsb = (ncell + (int64_t)GB * SCAN_ITEMS - 1) / ((int64_t)GB * SCAN_ITEMS);
-    if (int rc = ensure(ctx, sa, (size_t)m * (dim + 4) * sizeof(double) + 64)) return rc;   // sorted points | 32-byte records
+    if (int rc = ensure(ctx, sa, (size_t)m * (dim + 4) * sizeof(double) + 64 + kRecPad * 32)) return rc;   // sorted points | 32-byte records (+ pad)
     if (int rc = ensure(ctx, sb, (size_t)m * sizeof(int32_t) * 4)) return rc;     // sorted idx | codes | sorted codes | 0..m-1
     if (int rc = ensure(ctx, sc, (size_t)(ncell + 1) * sizeof(uint32_t) * 2)) return rc;  // start | count/fill
     if (int rc = ensure(ctx, sd, (size_t)(nsb + 1) * sizeof(uint32_t))) return rc;
@@ -1250,12 +1263,11 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
                                (const uint32_t *)ndef, ndef_next, (const uint32_t *)gb.inv, pos_mode ? 1 : 0, fR, ft); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
     } while (0)
-#define ICP_GQ(D, L, F) ICP_GQ2(D, L, F, 8, 4)
     static const int list8 = getenv("ICP_GRID_LIST8") ? atoi(getenv("ICP_GRID_LIST8")) : 0;
 #define ICP_GQL(D, L, F) \
     do { \
         if (list8) ICP_GQ2(D, L, F, 8, 4); \
-        else ICP_GQ2(D, L, F, 4, 4); \
+        else ICP_GQ2(D, L, F, 4, 3); \
     } while (0)
     if (gb.gp.dim == 3) {
         if (le) ICP_GQL(3, true, false);
@@ -1267,7 +1279,6 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
         else ICP_GQL(2, false, false);
     }
 #undef ICP_GQL
-#undef ICP_GQ
 #undef ICP_GQ2
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
