@@ -406,6 +406,7 @@ struct Deferred {
     int32_t q, level, bi;
     uint32_t bp;  // sorted position of the best record so far
     double best;
+    double s[3];  // the query as the per-lane pass searched it (moved, in the fused loop): saves the second pass a dependent load
 };
 
 // FUSED (the rigid loop from its second iteration on, kabsch.hip): the query is src[q] moved by the transform the last
@@ -577,6 +578,8 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             dq.bi = bi;
             dq.bp = bp;
             dq.best = best;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) dq.s[a] = a < DIM ? s[a] : 0.0;
             deferred[slot] = dq;
             return;
         }
@@ -740,15 +743,14 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 // width-32 shuffles, no LDS and no barrier: the two halves of a wave may be at different levels or out of work):
 // 2^20 x 2^20, 30 k deferred queries: 40 -> 34 us.
 template <int DIM, bool LE>
-__global__ __launch_bounds__(64) void grid_defer_kernel(const double *__restrict__ src, const double4 *__restrict__ recs,
+__global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restrict__ recs,
                                                         const uint32_t *__restrict__ start, GridParams gp,
                                                         const double *__restrict__ thr_in, int32_t *__restrict__ idx_out,
                                                         double *__restrict__ d2_out, const int32_t *__restrict__ done,
                                                         const Deferred *__restrict__ deferred,
                                                         const uint32_t *__restrict__ n_deferred,
                                                         uint32_t *__restrict__ next_counter,
-                                                        const uint32_t *__restrict__ inv, int pos_mode,
-                                                        const double *__restrict__ Rm, const double *__restrict__ tv) {
+                                                        const uint32_t *__restrict__ inv, int pos_mode, int jump) {
     // the two counters alternate between searches: nobody touches the other one during this search, so it is
     // cleared here for the next search (before the `done` test, so that it is clear whatever that says)
     if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0u;
@@ -763,26 +765,42 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double *__restrict
         const int64_t q = dq.q;
         double s[DIM];
 #pragma unroll
-        for (int a = 0; a < DIM; ++a) s[a] = src[q * DIM + a];
-        if (Rm) {   // fused rigid loop: the same moved query as in the per-lane pass
-            double o[DIM];
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) {
-                double v = s[0] * Rm[c];
-#pragma unroll
-                for (int k = 1; k < DIM; ++k) v += s[k] * Rm[k * DIM + c];
-                o[c] = v + tv[c];
-            }
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) s[c] = o[c];
-        }
+        for (int a = 0; a < DIM; ++a) s[a] = dq.s[a];
         int c0[DIM];
         cell_of<DIM>(s, gp, c0);
         double best = dq.best;     // group-uniform between levels
         int32_t bi = dq.bi;
         uint32_t bp = dq.bp;
         const double thr = LE ? thr_in[q] : 0.0;
-        for (int l = dq.level; l <= gp.bits; ++l) {
+        int l0 = dq.level;
+        if (!LE && jump && best < __builtin_inf()) {
+            // The bound the query arrives with (its hint: last iteration's match) already says how far the search has
+            // to reach: the first level whose 3^DIM box passes the gap test with it.  The best distance only shrinks,
+            // so that level's scan is the last one, and the levels below it -- subsets of its box -- add nothing:
+            // start there instead of climbing (one chain of dependent latencies instead of one per level).
+            for (; l0 < gp.bits; ++l0) {
+                const double hl = gp.h * (double)(1 << l0);
+                const int ncl = 1 << (gp.bits - l0);
+                const double slack_h = hl * 0x1p-20;
+                double mgap = __builtin_inf();
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) {
+                    const int ca = c0[a] >> l0;
+                    const double sl = slack_h + (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
+                    if (ca - 1 > 0) {
+                        const double g = s[a] - (gp.mn[a] + (double)(ca - 1) * hl) - sl;
+                        mgap = g < mgap ? g : mgap;
+                    }
+                    if (ca + 2 < ncl) {
+                        const double g = (gp.mn[a] + (double)(ca + 2) * hl) - s[a] - sl;
+                        mgap = g < mgap ? g : mgap;
+                    }
+                }
+                if (mgap == __builtin_inf()) break;                 // the box covers the grid
+                if (mgap > 0.0 && best < mgap * mgap) break;        // the same test as at the end of a level below
+            }
+        }
+        for (int l = l0; l <= gp.bits; ++l) {
             const double hl = gp.h * (double)(1 << l);
             const int ncl = 1 << (gp.bits - l);
             const double slack_h = hl * 0x1p-20;
@@ -1258,12 +1276,14 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
                            fa ? (double *)ctx->err_part.ptr : (double *)nullptr); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[1], st); \
         if (cap < 1000) \
-            hipLaunchKernelGGL((grid_defer_kernel<D, L>), dim3(nb2), dim3(64), 0, st, src, (const double4 *)gb.recs, \
+            hipLaunchKernelGGL((grid_defer_kernel<D, L>), dim3(nb2), dim3(64), 0, st, (const double4 *)gb.recs, \
                                (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (const Deferred *)dlist, \
-                               (const uint32_t *)ndef, ndef_next, (const uint32_t *)gb.inv, pos_mode ? 1 : 0, fR, ft); \
+                               (const uint32_t *)ndef, ndef_next, (const uint32_t *)gb.inv, pos_mode ? 1 : 0, \
+                               jump_env >= 0 ? jump_env : (hint ? 1 : 0)); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
     } while (0)
     static const int list8 = getenv("ICP_GRID_LIST8") ? atoi(getenv("ICP_GRID_LIST8")) : 0;
+    static const int jump_env = getenv("ICP_GRID_JUMP") ? atoi(getenv("ICP_GRID_JUMP")) : -1;   // default: with hints
 #define ICP_GQL(D, L, F) \
     do { \
         if (list8) ICP_GQ2(D, L, F, 8, 4); \
