@@ -52,7 +52,9 @@ struct icp_ctx {
     icp::Scratch work_a, work_b, work_c, work_d;  // general work arrays
     icp::Scratch grid_a, grid_b, grid_c, grid_d, grid_e;  // spatial grid over the target
     icp::Scratch sort_a, sort_b, sort_c, sort_d;          // Morton order of the queries
-    icp::Scratch sort_tmp;                                // temporary storage of the stable code sort (stablesort.hip)
+    // temporary storage of the stable code sort (stablesort.hip): one for a sorted source, one for a target above 4 M
+    // points -- icp_rigid_run builds the two orders on two streams at the same time, they must not share it
+    icp::Scratch sort_tmp, sort_tmp_tgt;
     icp::Scratch defer;                                   // grid search: queries handed to the wave-per-query pass
     icp::Scratch err_part;                                // fused rigid loop: per-block error sums of a search
     void *defer_cleared = nullptr;                        // buffer whose two counters are known to be in step
@@ -69,8 +71,8 @@ struct icp_ctx {
 namespace icp {
 int ensure(icp_ctx *ctx, Scratch &s, size_t bytes);
 int noalloc_init(icp_ctx *ctx);  // kabsch.hip
-int stable_sort_codes(icp_ctx *ctx, const uint32_t *codes_in, uint32_t *codes_out, int32_t *idx_tmp, int32_t *idx_out, int64_t m,
-                      int code_bits);  // stablesort.hip
+int stable_sort_codes(icp_ctx *ctx, Scratch &tmp, const uint32_t *codes_in, uint32_t *codes_out, int32_t *idx_tmp, int32_t *idx_out,
+                      int64_t m, int code_bits);  // stablesort.hip
 
 // spatial grid over a target cloud (grid.hip)
 struct GridParams {

@@ -1196,7 +1196,10 @@ int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBui
     // (beyond a few million points the scattered 56-byte writes of the unordered fill cost more than sort + gather:
     //  2^24 points 1.76 ms against 0.25 + 0.83; 2^20 points 68 us against 160 + 43)
     if (stable || force_stable || m > ((int64_t)1 << 22)) {
-        if (int rc = stable_sort_codes(ctx, codes, codes + m, (int32_t *)(codes + 2 * m), gb.sidx, m, dim * bits)) return rc;
+        // (a sorted source and a large target are built on two streams at once by icp_rigid_run: separate sort storage)
+        if (int rc = stable_sort_codes(ctx, stable ? ctx->sort_tmp : ctx->sort_tmp_tgt, codes, codes + m, (int32_t *)(codes + 2 * m),
+                                       gb.sidx, m, dim * bits))
+            return rc;
         if (dim == 3) hipLaunchKernelGGL(scatter_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, gb.spts, (const int32_t *)gb.sidx, (double4 *)gb.recs);
         else hipLaunchKernelGGL(scatter_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, gb.spts, (const int32_t *)gb.sidx, (double4 *)gb.recs);
     } else {

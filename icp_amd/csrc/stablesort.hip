@@ -22,7 +22,8 @@ __global__ void iota_kernel(int32_t *__restrict__ a, int64_t n) {
 }
 
 // idx_out = the permutation that sorts codes_in stably; codes_out = the sorted codes.  idx_tmp: m ints of scratch.
-int stable_sort_codes(icp_ctx *ctx, const uint32_t *codes_in, uint32_t *codes_out, int32_t *idx_tmp, int32_t *idx_out,
+// tmp: rocPRIM's temporary storage (grow-only; sorts that may run at the same time on two streams need one each).
+int stable_sort_codes(icp_ctx *ctx, Scratch &tmp, const uint32_t *codes_in, uint32_t *codes_out, int32_t *idx_tmp, int32_t *idx_out,
                       int64_t m, int code_bits) {
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, idx_tmp, m);
@@ -30,8 +31,8 @@ int stable_sort_codes(icp_ctx *ctx, const uint32_t *codes_in, uint32_t *codes_ou
     size_t bytes = 0;
     ICP_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, codes_in, codes_out, (const int32_t *)idx_tmp, idx_out, (size_t)m, 0u,
                                             (unsigned)code_bits, st));
-    if (int rc = ensure(ctx, ctx->sort_tmp, bytes + 256)) return rc;
-    ICP_HIP_CHECK(rocprim::radix_sort_pairs(ctx->sort_tmp.ptr, bytes, codes_in, codes_out, (const int32_t *)idx_tmp, idx_out, (size_t)m,
+    if (int rc = ensure(ctx, tmp, bytes + 256)) return rc;
+    ICP_HIP_CHECK(rocprim::radix_sort_pairs(tmp.ptr, bytes, codes_in, codes_out, (const int32_t *)idx_tmp, idx_out, (size_t)m,
                                             0u, (unsigned)code_bits, st));
     return ICP_OK;
 }

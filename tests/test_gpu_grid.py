@@ -256,3 +256,22 @@ def test_fused_loop_equals_unfused_loop(rigid, dim, use_tol, n):
     np.testing.assert_allclose(a["err_hist"].cpu().numpy()[:k], b["err_hist"].cpu().numpy()[:k], rtol=1e-13)
     a2 = rigid.rigid_icp(src, tgt, 1e-3, 25, use_tol=use_tol, want_idx=True, force_grid=True)
     assert torch.equal(a["err_hist"][:k], a2["err_hist"][:k])      # and reproducible bit for bit
+
+
+def test_large_target_and_sorted_source_are_built_concurrently(rigid):
+    """icp_rigid_run builds the Morton order of the source on a side stream while the target's grid is built on the
+    main one.  Above 4 M target points the target is ordered by the same radix sort as the source: the two sorts
+    run at the same time and used to share one temporary buffer (silently corrupting both orders once the buffer
+    no longer grew between them -- from the second call on, or at once when both clouds have the same size).
+    Two calls in a row against the full-scan loop."""
+    rng = np.random.default_rng(77)
+    m = (1 << 22) + 1000
+    tgt = rng.standard_normal((m, 3))
+    c, s = np.cos(0.1), np.sin(0.1)
+    R = np.array([[c, s, 0.0], [-s, c, 0.0], [0.0, 0.0, 1.0]])
+    src = ((tgt[rng.permutation(m)[:40000]] - 0.02) @ R)
+    b = rigid.rigid_icp(src, tgt, -np.inf, 3, want_idx=True, force_brute=True)
+    for _ in range(2):
+        a = rigid.rigid_icp(src, tgt, -np.inf, 3, want_idx=True)
+        assert np.array_equal(a["idx"].cpu().numpy(), b["idx"].cpu().numpy())
+        np.testing.assert_allclose(a["T"].cpu().numpy(), b["T"].cpu().numpy(), rtol=1e-12, atol=1e-13)
