@@ -742,6 +742,38 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 // records -> reduction), so two queries share a wave (32-lane groups; everything a group exchanges goes through
 // width-32 shuffles, no LDS and no barrier: the two halves of a wave may be at different levels or out of work):
 // 2^20 x 2^20, 30 k deferred queries: 40 -> 34 us.
+// cells on the deferred pass's stack: coordinates at their level (3-D: 9 bits each, 2-D: 14) and the level above them
+template <int DIM>
+__device__ __forceinline__ uint32_t pack_cell(const int *x, int lvl) {
+    if (DIM == 3) return ((uint32_t)lvl << 27) | ((uint32_t)x[2] << 18) | ((uint32_t)x[1] << 9) | (uint32_t)x[0];
+    return ((uint32_t)lvl << 28) | ((uint32_t)x[1] << 14) | (uint32_t)x[0];
+}
+template <int DIM>
+__device__ __forceinline__ void unpack_cell(uint32_t v, int *x, int &lvl) {
+    if (DIM == 3) {
+        lvl = (int)(v >> 27);
+        x[0] = (int)(v & 511u);
+        x[1] = (int)((v >> 9) & 511u);
+        x[2] = (int)((v >> 18) & 511u);
+    } else {
+        lvl = (int)(v >> 28);
+        x[0] = (int)(v & 16383u);
+        x[1] = (int)((v >> 14) & 16383u);
+    }
+}
+// LDS written by some lanes of a wave and read by others of the same wave: the hardware keeps a wave's LDS operations
+// in order, this keeps the compiler from moving them across each other
+__device__ __forceinline__ void lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#ifndef ICP_DEFER_G
+#define ICP_DEFER_G 32
+#endif
+constexpr int kSplit = 32;    // a cell above the finest level with more records than this is replaced by its children
+constexpr int kStack = 384;   // cells per group's stack (a cell whose children would not fit is scanned whole)
+
 template <int DIM, bool LE>
 __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restrict__ recs,
                                                         const uint32_t *__restrict__ start, GridParams gp,
@@ -750,13 +782,15 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
                                                         const Deferred *__restrict__ deferred,
                                                         const uint32_t *__restrict__ n_deferred,
                                                         uint32_t *__restrict__ next_counter,
-                                                        const uint32_t *__restrict__ inv, int pos_mode, int jump) {
+                                                        const uint32_t *__restrict__ inv, int pos_mode, int jump, int split_min) {
     // the two counters alternate between searches: nobody touches the other one during this search, so it is
     // cleared here for the next search (before the `done` test, so that it is clear whatever that says)
     if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0u;
     if (done && *done) return;
     constexpr int NBR = DIM == 3 ? 27 : 9;
-    constexpr int G = 32;  // lanes per query
+    constexpr int G = ICP_DEFER_G;  // lanes per query
+    constexpr uint32_t GMASK = G == 32 ? 0xffffffffu : ((1u << G) - 1u);
+    __shared__ uint32_t stk[64 / G][kStack];
     const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
     const uint32_t nd = *n_deferred;
     const uint32_t ngroups = gridDim.x * (64 / G);
@@ -804,96 +838,148 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
             const double hl = gp.h * (double)(1 << l);
             const int ncl = 1 << (gp.bits - l);
             const double slack_h = hl * 0x1p-20;
-            // lane nb < NBR: neighbour cell nb of the query's level-l cell
-            uint32_t r0 = 0, r1 = 0;
             int cl[DIM];
 #pragma unroll
             for (int a = 0; a < DIM; ++a) cl[a] = c0[a] >> l;
-            if (lane < NBR) {
-                const int off[3] = {lane % 3 - 1, (lane / 3) % 3 - 1, lane / 9 - 1};
-                bool inside = true;
-                double bound = 0.0;
+            // The 3^DIM cells of the query's level-l neighbourhood seed a stack of cells (packed coordinates + level,
+            // per group, in LDS).  Each round the group takes up to G cells off the top, one per lane: bound test, range
+            // lookup; a cell that holds more than kSplit records and is not at the finest level is replaced by its 2^DIM
+            // children (which are tested in their turn), the others are scanned together, G records per step.  A coarse
+            // cell that merely touches the query's ball therefore costs a descent along the ball's surface instead of
+            // a scan of everything in it (2^18-point Gaussian: a few rim queries used to scan tens of thousands of
+            // records each and held the whole pass for 0.1 ms).
+            int sp = 0;  // group-uniform
+#pragma unroll
+            for (int nb0 = 0; nb0 < NBR; nb0 += G) {
+                const int nb = nb0 + lane;
+                bool inside = nb < NBR;
                 int x[DIM];
+                const int off[3] = {nb % 3 - 1, (nb / 3) % 3 - 1, nb / 9 - 1};
 #pragma unroll
                 for (int a = 0; a < DIM; ++a) {
                     x[a] = cl[a] + off[a];
                     inside = inside && x[a] >= 0 && x[a] < ncl;
-                    const double sl = slack_h + (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
-                    const double lo = gp.mn[a] + (double)x[a] * hl, hi = gp.mn[a] + (double)(x[a] + 1) * hl;
-                    double g = lo - s[a] - sl;
-                    double gh = s[a] - hi - sl;
-                    open_sides(gp, a, x[a], ncl, g, gh);
-                    g = gh > g ? gh : g;
-                    g = g > 0.0 ? g : 0.0;
-                    bound = bound + g * g;   // same association as the per-lane pass: ((gx + gy) + gz)
                 }
-                if (inside && !(LE ? (bound > thr) : (bound > best))) {
-                    const uint32_t code = morton<DIM>(x);
-                    r0 = start[(uint64_t)code << (DIM * l)];
-                    r1 = start[((uint64_t)code + 1) << (DIM * l)];
-                }
+                const uint32_t gm = (uint32_t)(__ballot(inside) >> (grp * G)) & GMASK;
+                if (inside) stk[grp][sp + __popc(gm & ((1u << lane) - 1u))] = pack_cell<DIM>(x, l);
+                sp += __popc(gm);
             }
-            // prefix of the range lengths over the group's lanes (lanes >= NBR hold empty ranges)
-            const uint32_t len = r1 - r0;
-            uint32_t incl = len;
+            while (sp > 0) {
+                lds_wave_sync();
+                const int take = sp < G ? sp : G;
+                sp -= take;
+                uint32_t r0 = 0, r1 = 0;
+                int lvl = 0, x[DIM];
 #pragma unroll
-            for (int o = 1; o < G; o <<= 1) {
-                const uint32_t v = __shfl_up(incl, o, G);
-                if (lane >= o) incl += v;
-            }
-            const uint32_t excl = incl - len;                      // records before cell `lane`
-            const uint32_t total = __shfl(incl, G - 1, G);
-            double lb = best;
-            int32_t li = bi;
-            uint32_t lp = bp;
-            for (uint32_t base = 0; base < total; base += G) {      // group-uniform trip count: the shuffles need every lane
-                const uint32_t tpos = base + lane;
-                int c = 0;  // last cell with excl[c] <= tpos
+                for (int a = 0; a < DIM; ++a) x[a] = 0;
+                if (lane < take) {
+                    unpack_cell<DIM>(stk[grp][sp + lane], x, lvl);
+                    const double hv = gp.h * (double)(1 << lvl);
+                    const int nv = 1 << (gp.bits - lvl);
+                    const double slv = hv * 0x1p-20;
+                    double bound = 0.0;
 #pragma unroll
-                for (int stp = 16; stp > 0; stp >>= 1) {
-                    const int cc = c + stp < NBR ? c + stp : NBR - 1;
-                    const uint32_t e = __shfl(excl, cc, G);
-                    if (c + stp < NBR && e <= tpos) c += stp;
-                }
-                const uint32_t rc0 = __shfl(r0, c, G), ex = __shfl(excl, c, G);
-                if (tpos < total) {
-                    const uint32_t rpos = rc0 + (tpos - ex);
-                    const double4 rc = recs[rpos];
-                    const double dx = rc.x - s[0], dy = rc.y - s[1];
-                    double d = dx * dx + dy * dy;
-                    if (DIM == 3) {
-                        const double dz = rc.z - s[2];
-                        d = d + dz * dz;
+                    for (int a = 0; a < DIM; ++a) {
+                        const double sl = slv + (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
+                        const double lo = gp.mn[a] + (double)x[a] * hv, hi = gp.mn[a] + (double)(x[a] + 1) * hv;
+                        double g = lo - s[a] - sl;
+                        double gh = s[a] - hi - sl;
+                        open_sides(gp, a, x[a], nv, g, gh);
+                        g = gh > g ? gh : g;
+                        g = g > 0.0 ? g : 0.0;
+                        bound = bound + g * g;   // same association as the per-lane pass: ((gx + gy) + gz)
                     }
-                    const int32_t id = (int32_t)__double_as_longlong(rc.w);
-                    if (LE) {
-                        if (d <= thr && id < li) {
+                    if (!(LE ? (bound > thr) : (bound > best))) {
+                        const uint32_t code = morton<DIM>(x);
+                        r0 = start[(uint64_t)code << (DIM * lvl)];
+                        r1 = start[((uint64_t)code + 1) << (DIM * lvl)];
+                    }
+                }
+                lds_wave_sync();   // every lane has read its cell before children are written over the same slots
+                uint32_t len = r1 - r0;
+                // split: children pushed in lane order; a cell whose children would not fit is scanned whole
+                constexpr int NCH = 1 << DIM;
+                bool split = lvl > 0 && len > (uint32_t)split_min;
+                {
+                    const uint32_t sm = (uint32_t)(__ballot(split) >> (grp * G)) & GMASK;
+                    const int rank = __popc(sm & ((1u << lane) - 1u));
+                    if (split && sp + (rank + 1) * NCH > kStack) split = false;
+                }
+                const uint32_t sm = (uint32_t)(__ballot(split) >> (grp * G)) & GMASK;
+                if (split) {
+                    const int at = sp + __popc(sm & ((1u << lane) - 1u)) * NCH;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        int y[DIM];
+#pragma unroll
+                        for (int a = 0; a < DIM; ++a) y[a] = 2 * x[a] + ((c >> a) & 1);
+                        stk[grp][at + c] = pack_cell<DIM>(y, lvl - 1);
+                    }
+                    len = 0;
+                }
+                sp += __popc(sm) * NCH;
+                // prefix of the range lengths over the group's lanes
+                uint32_t incl = len;
+#pragma unroll
+                for (int o = 1; o < G; o <<= 1) {
+                    const uint32_t v = __shfl_up(incl, o, G);
+                    if (lane >= o) incl += v;
+                }
+                const uint32_t excl = incl - len;                      // records before this lane's cell
+                const uint32_t total = __shfl(incl, G - 1, G);
+                double lb = best;
+                int32_t li = bi;
+                uint32_t lp = bp;
+                for (uint32_t base = 0; base < total; base += G) {      // group-uniform trip count: the shuffles need every lane
+                    const uint32_t tpos = base + lane;
+                    int c = 0;  // last lane with excl[c] <= tpos
+#pragma unroll
+                    for (int stp = G / 2; stp > 0; stp >>= 1) {
+                        const uint32_t e = __shfl(excl, c + stp, G);    // (c + stp < G always: c <= G - 2 * stp before the step)
+                        if (e <= tpos) c += stp;
+                    }
+                    const uint32_t rc0 = __shfl(r0, c, G), ex = __shfl(excl, c, G);
+                    if (tpos < total) {
+                        const uint32_t rpos = rc0 + (tpos - ex);
+                        const double4 rc = recs[rpos];
+                        const double dx = rc.x - s[0], dy = rc.y - s[1];
+                        double d = dx * dx + dy * dy;
+                        if (DIM == 3) {
+                            const double dz = rc.z - s[2];
+                            d = d + dz * dz;
+                        }
+                        const int32_t id = (int32_t)__double_as_longlong(rc.w);
+                        if (LE) {
+                            if (d <= thr && id < li) {
+                                li = id;
+                                lp = rpos;
+                                lb = 0.0;
+                            }
+                        } else if (d < lb || (d == lb && id < li)) {
+                            lb = d;
                             li = id;
                             lp = rpos;
-                            lb = 0.0;
                         }
-                    } else if (d < lb || (d == lb && id < li)) {
-                        lb = d;
-                        li = id;
-                        lp = rpos;
                     }
                 }
-            }
-            // group argmin of (d2, index); the position rides along
+                if (total > 0) {
+                    // group argmin of (d2, index); the position rides along
 #pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) {
-                const double ob = shfl_xor_f64(lb, o);
-                const int32_t oi = __shfl_xor(li, o, 64);
-                const uint32_t op = (uint32_t)__shfl_xor((int)lp, o, 64);
-                if (ob < lb || (ob == lb && oi < li)) {
-                    lb = ob;
-                    li = oi;
-                    lp = op;
+                    for (int o = G / 2; o > 0; o >>= 1) {
+                        const double ob = shfl_xor_f64(lb, o);
+                        const int32_t oi = __shfl_xor(li, o, 64);
+                        const uint32_t op = (uint32_t)__shfl_xor((int)lp, o, 64);
+                        if (ob < lb || (ob == lb && oi < li)) {
+                            lb = ob;
+                            li = oi;
+                            lp = op;
+                        }
+                    }
+                    best = lb;
+                    bi = li;
+                    bp = lp;
                 }
             }
-            best = lb;
-            bi = li;
-            bp = lp;
             if (ncl == 1) break;
             double mgap = __builtin_inf();
 #pragma unroll
@@ -1282,11 +1368,12 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
             hipLaunchKernelGGL((grid_defer_kernel<D, L>), dim3(nb2), dim3(64), 0, st, (const double4 *)gb.recs, \
                                (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (const Deferred *)dlist, \
                                (const uint32_t *)ndef, ndef_next, (const uint32_t *)gb.inv, pos_mode ? 1 : 0, \
-                               jump_env >= 0 ? jump_env : (hint ? 1 : 0)); \
+                               jump_env >= 0 ? jump_env : (hint ? 1 : 0), split_env); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
     } while (0)
     static const int list8 = getenv("ICP_GRID_LIST8") ? atoi(getenv("ICP_GRID_LIST8")) : 0;
     static const int jump_env = getenv("ICP_GRID_JUMP") ? atoi(getenv("ICP_GRID_JUMP")) : -1;   // default: with hints
+    static const int split_env = getenv("ICP_GRID_SPLIT") ? atoi(getenv("ICP_GRID_SPLIT")) : kSplit;
 #define ICP_GQL(D, L, F) \
     do { \
         if (list8) ICP_GQ2(D, L, F, 8, 4); \
