@@ -66,6 +66,7 @@ struct icp_ctx {
     hipEvent_t order_ev = nullptr;  // icp_ctx_set_stream: orders a new stream after the work queued on the previous one
     // this device's address of kabsch.hip's file-scope scratch array (icp_find_transform_noalloc)
     double *noalloc_scratch = nullptr;
+    void *pinned = nullptr;  // 1 KB of pinned host memory: asynchronous read-back of the grid statistics (grid.hip)
 };
 
 namespace icp {
@@ -96,6 +97,18 @@ struct GridBuild {
 };
 // slot 0: target grid (grid_* scratch); slot 1: query ordering (sort_* scratch)
 int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, int slot = 0);
+// the two halves of a build (grid.hip): statistics + asynchronous read-back | everything after the read-back
+struct GridPending {
+    const double *pts = nullptr;
+    int64_t m = 0;
+    int dim = 0, ns = 0;
+    bool stable = false, robust = false, adaptive = false;
+    void *host = nullptr;   // pinned copy of the statistics record
+    Scratch *sa = nullptr, *sb = nullptr, *sc = nullptr, *sd = nullptr;
+};
+int grid_build_begin(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, Scratch &sa, Scratch &sb,
+                     Scratch &sc, Scratch &sd, bool stable, GridPending &pend);
+int grid_build_finish(icp_ctx *ctx, const GridPending &pend, GridBuild &gb);
 // same, into caller-owned scratch (persistent target handles)
 int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, Scratch &sa, Scratch &sb,
                     Scratch &sc, Scratch &sd, bool stable = false);

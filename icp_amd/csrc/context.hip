@@ -75,6 +75,7 @@ extern "C" int icp_ctx_destroy(icp_ctx *ctx) {
         (void)hipStreamSynchronize(ctx->side);
         (void)hipStreamDestroy(ctx->side);
     }
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->side_ev) (void)hipEventDestroy(ctx->side_ev);
     if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
     delete ctx;

@@ -1167,14 +1167,38 @@ int grid_build(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &g
     return grid_build_into(ctx, tgt, m, dim, gb, ctx->grid_a, ctx->grid_b, ctx->grid_c, ctx->grid_d, false);
 }
 
+static double grid_clip() {
+    static const double clip = getenv("ICP_GRID_CLIP") ? atof(getenv("ICP_GRID_CLIP")) : 0.3;
+    return clip;
+}
+static double grid_occ_target() {
+    static const double occ_target = getenv("ICP_GRID_OCC") ? atof(getenv("ICP_GRID_OCC")) : 5.0;
+    return occ_target;
+}
+
 int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, Scratch &sa, Scratch &sb,
                     Scratch &sc, Scratch &sd, bool stable) {
+    GridPending pend;
+    if (int rc = grid_build_begin(ctx, tgt, m, dim, gb, sa, sb, sc, sd, stable, pend)) return rc;
+    return grid_build_finish(ctx, pend, gb);
+}
+
+// First half of a build: the statistics kernels (bounding box; for a target also the sample quantiles and cell
+// populations) and their copy to pinned host memory, all asynchronous on ctx->stream.  grid_build_finish() waits for
+// that copy and enqueues the rest.  Split so that icp_rigid_run can start the statistics of the target and of the
+// source on two streams before it waits for either (build_grids in kabsch.hip); a sorted source (stable) and a target
+// use disjoint scratch for this half.
+int grid_build_begin(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, Scratch &sa, Scratch &sb,
+                     Scratch &sc, Scratch &sd, bool stable, GridPending &pend) {
     hipStream_t st = ctx->stream;
     gb.usable = false;
     if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
     if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
-    double *part = (double *)ctx->partials.ptr;
-    BBox *dbox = (BBox *)((double *)ctx->small.ptr + 400);
+    if (!ctx->pinned) ICP_HIP_CHECK(hipHostMalloc(&ctx->pinned, 1024, hipHostMallocDefault));
+    static_assert(sizeof(BBox) <= 256 && 440 * 8 + sizeof(BBox) <= 4096 && 1024 * 8 * 2 <= kMaxPartials * kSumSlots,
+                  "scratch of the two concurrent builds overlaps");
+    double *part = (double *)ctx->partials.ptr + (stable ? 1024 * 8 : 0);
+    BBox *dbox = (BBox *)((double *)ctx->small.ptr + (stable ? 440 : 400));
     int nb = (int)((m + GB - 1) / GB);
     if (nb > 1024) nb = 1024;
     if (dim == 3) hipLaunchKernelGGL(bbox_kernel<3>, dim3(nb), dim3(GB), 0, st, tgt, m, part);
@@ -1187,18 +1211,44 @@ int grid_build_into(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBui
     // the 1 % .. 99 % order statistics of a fixed-stride sample of 4096 points widened by `clip` of their distance on each side
     // (and never more than the bounding box); points beyond are clamped into the border columns, which the searches
     // treat as unbounded outwards (open_sides).  Exactness does not depend on where the extents are.
-    static const double clip = getenv("ICP_GRID_CLIP") ? atof(getenv("ICP_GRID_CLIP")) : 0.3;
+    const double clip = grid_clip();
     const int ns = (int)std::min<int64_t>(kQuantSamples, m);
     const bool robust = clip >= 0.0 && ns >= 64 && !stable;  // (a sorted SOURCE only needs an order: any extents do)
     if (robust)  // (same stream, after bbox_final_kernel: it adds its six numbers to the same record)
         hipLaunchKernelGGL(quantile_kernel, dim3(dim), dim3(1024), 0, st, tgt, m / ns, ns, dim, std::max(1, ns / 100), dbox);
-    static const double occ_target = getenv("ICP_GRID_OCC") ? atof(getenv("ICP_GRID_OCC")) : 5.0;
-    const bool adaptive = robust && env_bits() <= 0 && occ_target > 0.0;
+    const bool adaptive = robust && env_bits() <= 0 && grid_occ_target() > 0.0;
     if (adaptive) hipLaunchKernelGGL(occupancy_kernel, dim3(1), dim3(1024), 0, st, tgt, m / ns, ns, dim, clip, dbox);
     ICP_HIP_CHECK(hipGetLastError());
-    BBox hb;
-    ICP_HIP_CHECK(hipMemcpyAsync(&hb, dbox, sizeof(BBox), hipMemcpyDeviceToHost, st));
+    void *host = (char *)ctx->pinned + (stable ? 512 : 0);
+    ICP_HIP_CHECK(hipMemcpyAsync(host, dbox, sizeof(BBox), hipMemcpyDeviceToHost, st));
+    pend.pts = tgt;
+    pend.m = m;
+    pend.dim = dim;
+    pend.stable = stable;
+    pend.robust = robust;
+    pend.adaptive = adaptive;
+    pend.ns = ns;
+    pend.host = host;
+    pend.sa = &sa;
+    pend.sb = &sb;
+    pend.sc = &sc;
+    pend.sd = &sd;
+    return ICP_OK;
+}
+
+// Second half: waits for the statistics (ctx->stream must be the stream grid_build_begin ran on), fixes the grid's
+// extents and resolution on the host and enqueues the counting sort.
+int grid_build_finish(icp_ctx *ctx, const GridPending &pend, GridBuild &gb) {
+    hipStream_t st = ctx->stream;
+    const double *tgt = pend.pts;
+    const int64_t m = pend.m;
+    const int dim = pend.dim, ns = pend.ns;
+    const bool stable = pend.stable, robust = pend.robust, adaptive = pend.adaptive;
+    Scratch &sa = *pend.sa, &sb = *pend.sb, &sc = *pend.sc, &sd = *pend.sd;
+    const double clip = grid_clip(), occ_target = grid_occ_target();
     ICP_HIP_CHECK(hipStreamSynchronize(st));
+    BBox hb;
+    std::memcpy(&hb, pend.host, sizeof(BBox));
     if (hb.bad) return ICP_OK;  // NaN / inf in the target: caller uses the brute-force scan
     int open = 0;
     for (int a = 0; robust && a < dim; ++a) {

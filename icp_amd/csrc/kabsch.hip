@@ -680,18 +680,24 @@ static int build_grids(icp_ctx *ctx, const double *src, int64_t n, const double 
     if (!side_ok) (void)hipGetLastError();
     hipStream_t main_stream = ctx->stream;
     if (sort_source && side_ok) {
+        // statistics of both clouds first (8 launches), then the two read-backs: while the host enqueues the ~30 launches
+        // of the source's sort, the GPU is already through the target's sample statistics (set-up 0.62 -> see DESIGN.md 3.1b)
+        GridPending ps, pt;
         ICP_HIP_CHECK(hipEventRecord(ctx->side_ev, main_stream));      // whatever produced src is queued on the main stream
         ICP_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));
+        if (int rc = grid_build_begin(ctx, tgt, m, dim, grid, ctx->grid_a, ctx->grid_b, ctx->grid_c, ctx->grid_d, false, pt)) return rc;
         ctx->stream = ctx->side;
-        const int rc = grid_build(ctx, src, n, dim, qsort, 1);
+        int rc = grid_build_begin(ctx, src, n, dim, qsort, ctx->sort_a, ctx->sort_b, ctx->sort_c, ctx->sort_d, true, ps);
+        if (!rc) rc = grid_build_finish(ctx, ps, qsort);
         ctx->stream = main_stream;
         if (rc) return rc;
-    }
-    if (int rc = grid_build(ctx, tgt, m, dim, grid)) return rc;
-    if (sort_source && side_ok) {
+        if ((rc = grid_build_finish(ctx, pt, grid))) return rc;
         ICP_HIP_CHECK(hipEventRecord(ctx->side_ev, ctx->side));
         ICP_HIP_CHECK(hipStreamWaitEvent(main_stream, ctx->side_ev, 0));
-    } else if (sort_source && grid.usable) {
+        return ICP_OK;
+    }
+    if (int rc = grid_build(ctx, tgt, m, dim, grid)) return rc;
+    if (sort_source && grid.usable) {
         if (int rc = grid_build(ctx, src, n, dim, qsort, 1)) return rc;
     }
     return ICP_OK;
