@@ -12,6 +12,9 @@
 // reference applies no reflection fix (Q2) and neither does this.
 #include <vector>
 
+#include <chrono>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace icp {
@@ -878,7 +881,15 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
     // valid sum order); only the user-visible correspondences are scattered back to the caller's order.
     GridBuild grid, qsort;
     const int32_t *order = nullptr;
+    static const bool timing = getenv("ICP_RIGID_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tt0 = timing ? now() : 0.0;
     if (int rc = build_grids(ctx, src, n, tgt, m, dim, flags, grid, qsort)) return rc;
+    if (timing) {
+        const double t1 = now();
+        (void)hipStreamSynchronize(ctx->stream);
+        std::fprintf(stderr, "rigid_loop: build_grids host %.0f us, +sync %.0f us\n", t1 - tt0, now() - tt0);
+    }
     if (!grid.usable) flags |= ICP_FORCE_BRUTE;
     if (grid.usable && qsort.usable) {
         src = qsort.spts;
@@ -958,6 +969,11 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
                            pos ? (const int32_t *)grid.sidx : (const int32_t *)nullptr, n, idx_out);
     hipLaunchKernelGGL(rigid_finish_kernel, dim3(1), dim3(1), 0, s, (const RigidState *)st, dim, T_out_dev, iters_out_dev);
     ICP_HIP_CHECK(hipGetLastError());
+    if (timing) {
+        const double t1 = now();
+        (void)hipStreamSynchronize(ctx->stream);
+        std::fprintf(stderr, "rigid_loop: all enqueued at %.0f us, done at %.0f us (%d iterations)\n", t1 - tt0, now() - tt0, max_iter);
+    }
     return ICP_OK;
 }
 }  // namespace icp
