@@ -275,3 +275,30 @@ def test_large_target_and_sorted_source_are_built_concurrently(rigid):
         a = rigid.rigid_icp(src, tgt, -np.inf, 3, want_idx=True)
         assert np.array_equal(a["idx"].cpu().numpy(), b["idx"].cpu().numpy())
         np.testing.assert_allclose(a["T"].cpu().numpy(), b["T"].cpu().numpy(), rtol=1e-12, atol=1e-13)
+
+
+def test_deferred_pass_descends_into_coarse_cells(rigid):
+    """Rim and far-away queries of a dense cloud: their balls reach coarse cells that hold tens of thousands of
+    records; the deferred pass replaces such cells by their children (a stack per half-wave in LDS, several levels
+    deep here, cells that do not fit on it scanned whole) instead of scanning them.  Exact all the same: indices and
+    squared distances against the full scan, 3-D and 2-D, with and without hints, and it must not take the seconds a
+    whole-cell scan per query would."""
+    import time
+    import torch
+    rng = np.random.default_rng(91)
+    for dim in (3, 2):
+        tgt = np.concatenate([rng.standard_normal((300000, dim)) * 0.05, rng.standard_normal((200, dim)) * 30.0])
+        d = rng.standard_normal((40000, dim))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        src = np.concatenate([d[:20000] * rng.uniform(0.2, 0.6, (20000, 1)),        # the rim of the dense cloud
+                              d[20000:35000] * rng.uniform(1.0, 100.0, (15000, 1)),  # far outside it
+                              rng.standard_normal((5000, dim)) * 0.05])              # inside
+        bi, bd = rigid.closest_indices(src, tgt, want_d2=True, force_brute=True)
+        gi, gd = rigid.closest_indices(src, tgt, want_d2=True, force_grid=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gi2, gd2 = rigid.closest_indices(src, tgt, want_d2=True, force_grid=True, hint=bi)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert torch.equal(gi, bi) and torch.equal(gd, bd) and torch.equal(gi2, bi) and torch.equal(gd2, bd)
+        assert dt < 0.5, dt
