@@ -1418,11 +1418,13 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
             hipLaunchKernelGGL((grid_defer_kernel<D, L>), dim3(nb2), dim3(64), 0, st, (const double4 *)gb.recs, \
                                (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (const Deferred *)dlist, \
                                (const uint32_t *)ndef, ndef_next, (const uint32_t *)gb.inv, pos_mode ? 1 : 0, \
-                               jump_env >= 0 ? jump_env : (hint ? 1 : 0), split_env); \
+                               jump_env >= 0 ? jump_env : ((hint && pos_mode) ? 1 : 0), split_env); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
     } while (0)
     static const int list8 = getenv("ICP_GRID_LIST8") ? atoi(getenv("ICP_GRID_LIST8")) : 0;
-    static const int jump_env = getenv("ICP_GRID_JUMP") ? atoi(getenv("ICP_GRID_JUMP")) : -1;   // default: with hints
+    // default: inside the rigid loops, whose hints are last iteration's matches (positions); a caller's ICP_HINT_IDX
+    // may be anything, and a poor bound would make the jump scan far more than the climb
+    static const int jump_env = getenv("ICP_GRID_JUMP") ? atoi(getenv("ICP_GRID_JUMP")) : -1;
     static const int split_env = getenv("ICP_GRID_SPLIT") ? atoi(getenv("ICP_GRID_SPLIT")) : kSplit;
 #define ICP_GQL(D, L, F) \
     do { \
