@@ -143,8 +143,40 @@ __device__ __forceinline__ void open_sides(const GridParams &gp, int a, int x, i
 }
 
 // Block a sorts the a-th coordinate of ns <= 4096 points taken at a fixed stride (bitonic network in LDS) and writes its
-// k-th smallest and k-th largest value: the quantiles that set the extents of the grid.  Deterministic.
+// LDS written by some lanes of a wave and read by others of the same wave: the hardware keeps a wave's LDS operations
+// in order, this keeps the compiler from moving them across each other
+__device__ __forceinline__ void lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Bitonic sort of kQuantSamples values in LDS by a 1024-thread block.  Thread t of a stage touches elements inside
+// the 128-element chunk of its wave's 64 consecutive pairs whenever the stride is at most 64, so only the 15 stages
+// with longer strides (and the stage before each of them) need the block barrier: the other 63 of the 78 stages order
+// their LDS traffic inside the wave (quantile_kernel 48 -> see DESIGN.md 3.1b; the block runs on one compute unit and
+// its barriers were its run time).
 constexpr int kQuantSamples = 4096;
+template <typename T>
+__device__ __forceinline__ void bitonic_sort_lds(T *v) {
+    for (int size = 2; size <= kQuantSamples; size <<= 1)
+        for (int ls = 31 - __builtin_clz(size >> 1); ls >= 0; --ls) {   // stride 2^ls: shifts, no integer division --
+            const int str = 1 << ls;                                     // the block runs on ONE compute unit and its
+            for (int t = threadIdx.x; t < kQuantSamples / 2; t += blockDim.x) {   // instructions are its run time
+                const int lo = ((t >> ls) << (ls + 1)) + (t & (str - 1)), hi = lo + str;
+                const bool up = ((lo & size) == 0);
+                const T x = v[lo], y = v[hi];
+                if ((x > y) == up) {
+                    v[lo] = y;
+                    v[hi] = x;
+                }
+            }
+            if (str >= 128 || (str == 1 && size >= 128)) __syncthreads();
+            else lds_wave_sync();
+        }
+}
+
+// k-th smallest and k-th largest value: the quantiles that set the extents of the grid.  Deterministic.
 __global__ __launch_bounds__(1024) void quantile_kernel(const double *__restrict__ p, int64_t stride, int ns, int dim, int k,
                                                         BBox *__restrict__ out) {
     __shared__ double v[kQuantSamples];
@@ -152,19 +184,7 @@ __global__ __launch_bounds__(1024) void quantile_kernel(const double *__restrict
     for (int i = threadIdx.x; i < kQuantSamples; i += blockDim.x)
         v[i] = i < ns ? p[(int64_t)i * stride * dim + a] : __builtin_inf();
     __syncthreads();
-    for (int size = 2; size <= kQuantSamples; size <<= 1)
-        for (int str = size >> 1; str > 0; str >>= 1) {
-            for (int t = threadIdx.x; t < kQuantSamples / 2; t += blockDim.x) {
-                const int lo = (t / str) * 2 * str + (t % str), hi = lo + str;
-                const bool up = ((lo & size) == 0);
-                const double x = v[lo], y = v[hi];
-                if ((x > y) == up) {
-                    v[lo] = y;
-                    v[hi] = x;
-                }
-            }
-            __syncthreads();
-        }
+    bitonic_sort_lds(v);
     if (threadIdx.x == 0) {
         out->qlo[a] = v[k];
         out->qhi[a] = v[ns - 1 - k];
@@ -214,19 +234,7 @@ __global__ __launch_bounds__(1024) void occupancy_kernel(const double *__restric
         code[i] = c;
     }
     __syncthreads();
-    for (int size = 2; size <= kQuantSamples; size <<= 1)
-        for (int str = size >> 1; str > 0; str >>= 1) {
-            for (int t = threadIdx.x; t < kQuantSamples / 2; t += blockDim.x) {
-                const int lo = (t / str) * 2 * str + (t % str), hi = lo + str;
-                const bool up = ((lo & size) == 0);
-                const uint32_t x = code[lo], y = code[hi];
-                if ((x > y) == up) {
-                    code[lo] = y;
-                    code[hi] = x;
-                }
-            }
-            __syncthreads();
-        }
+    bitonic_sort_lds(code);
     // one walk over the (at most 32) predecessors of every sample serves all levels: two codes share a level-l cell iff
     // they agree above dim*l bits, i.e. from level ceil(bitlength(a ^ b) / dim) upwards
     // (per thread at most 4 x 32 pairs: the counts per first-shared level fit 8-bit fields of two 64-bit words; the
@@ -760,13 +768,6 @@ __device__ __forceinline__ void unpack_cell(uint32_t v, int *x, int &lvl) {
         x[0] = (int)(v & 16383u);
         x[1] = (int)((v >> 14) & 16383u);
     }
-}
-// LDS written by some lanes of a wave and read by others of the same wave: the hardware keeps a wave's LDS operations
-// in order, this keeps the compiler from moving them across each other
-__device__ __forceinline__ void lds_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 #ifndef ICP_DEFER_G
 #define ICP_DEFER_G 32
