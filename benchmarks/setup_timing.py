@@ -11,3 +11,8 @@ for k in (2,1,1,1,30,30):
     torch.cuda.synchronize(); t0=time.perf_counter()
     r=rigid.rigid_icp(s,t,0.0,k,use_tol=False,want_idx=True,ctx=ctx)
     torch.cuda.synchronize(); print(k,'python wall %.0f us'%((time.perf_counter()-t0)*1e6),flush=True)
+# do the first calls of a process run slower?  (host clock inside the library: entry -> GPU done)
+for k in [20] * 10:
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    r = rigid.rigid_icp(s, t, 0.0, k, use_tol=False, want_idx=True, ctx=ctx)
+    torch.cuda.synchronize(); print(k, 'python wall %.0f us' % ((time.perf_counter() - t0) * 1e6), flush=True)
