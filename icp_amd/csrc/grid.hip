@@ -1019,6 +1019,9 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
 // inserted twice); a cell is skipped when fl(sqrt(bound)) > k-th key and the search ends when the
 // k-th key is strictly below fl(sqrt(gap^2)): sqrt and its rounding are monotone, so every unvisited
 // record has a key >= that, and an equal key would still have to be looked at for its index.
+constexpr int kKnnSplit = 64;   // records: a cell above the finest level with more is descended into, not scanned
+constexpr int kKnnStack = 64;   // cells on a lane's stack
+
 template <int DIM, int K>
 __global__ __launch_bounds__(GB) void grid_knn_kernel(const double *__restrict__ qpts, int64_t nq,
                                                      const double4 *__restrict__ recs, const uint32_t *__restrict__ start,
@@ -1055,32 +1058,27 @@ __global__ __launch_bounds__(GB) void grid_knn_kernel(const double *__restrict__
             int cl[DIM];
 #pragma unroll
             for (int a = 0; a < DIM; ++a) cl[a] = c0[a] >> l;
-            for (int step = 0; step < NBR; ++step) {
-                // own cell first: it fills the list and makes the bound test bite
-                const int nb = step == 0 ? NBR / 2 : (step <= NBR / 2 ? step - 1 : step);
-                const int off[3] = {nb % 3 - 1, (nb / 3) % 3 - 1, nb / 9 - 1};
-                bool inside = true;
+            // lower bound of the squared distance to cell y of level lv (the arithmetic of the searches above)
+            auto cell_bound = [&](const int *y, int lv) {
+                const double hv = gp.h * (double)(1 << lv);
+                const int nv = 1 << (gp.bits - lv);
+                const double slv = hv * 0x1p-20;
                 double bound = 0.0;
-                int x[DIM];
 #pragma unroll
                 for (int a = 0; a < DIM; ++a) {
-                    x[a] = cl[a] + off[a];
-                    inside = inside && x[a] >= 0 && x[a] < ncl;
-                    const double sl = slack_h + (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
-                    const double lo = gp.mn[a] + (double)x[a] * hl, hi = gp.mn[a] + (double)(x[a] + 1) * hl;
+                    const double sl = slv + (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
+                    const double lo = gp.mn[a] + (double)y[a] * hv, hi = gp.mn[a] + (double)(y[a] + 1) * hv;
                     double g = lo - s[a] - sl;
                     double gh = s[a] - hi - sl;
-                    open_sides(gp, a, x[a], ncl, g, gh);
+                    open_sides(gp, a, y[a], nv, g, gh);
                     g = gh > g ? gh : g;
                     g = g > 0.0 ? g : 0.0;
                     bound = bound + g * g;
                 }
-                if (!inside) continue;
-                if (__dsqrt_rn(bound) > key[K - 1]) continue;
-                const uint32_t code = morton<DIM>(x);
-                const uint32_t p0 = start[(uint64_t)code << (DIM * l)], p1 = start[((uint64_t)code + 1) << (DIM * l)];
-                for (uint32_t p = p0; p < p1; ++p) {
-                    const double4 rc = recs[p];
+                return bound;
+            };
+            auto consider = [&](const double4 &rc) {
+                {
                     double d2 = 0.0;
                     {
                         const double dx = rc.x - s[0], dy = rc.y - s[1];
@@ -1091,10 +1089,10 @@ __global__ __launch_bounds__(GB) void grid_knn_kernel(const double *__restrict__
                             d2 += dz * dz;
                         }
                     }
-                    if (!(d2 <= gate)) continue;
+                    if (!(d2 <= gate)) return;
                     const double r = __dsqrt_rn(d2);
                     const int32_t jj = (int32_t)__double_as_longlong(rc.w);
-                    if (!(r < key[K - 1] || (r == key[K - 1] && jj < id[K - 1]))) continue;
+                    if (!(r < key[K - 1] || (r == key[K - 1] && jj < id[K - 1]))) return;
                     double ck = r;
                     int32_t ci = jj;
                     bool shifting = false;
@@ -1114,6 +1112,76 @@ __global__ __launch_bounds__(GB) void grid_knn_kernel(const double *__restrict__
                     // order here, so an EQUAL root must get through too (it may carry a lower index): the
                     // class of d2 values that round to kr ends below kr^2 (1 + 2^-52), hence the margin.
                     gate = (kr > 1e-150 && kr < 1e150) ? kr * kr * (1.0 + 0x1p-50) : __builtin_inf();
+                }
+            };
+            // records of a range four at a time: the loads of a group are in flight together (one lane walking a long
+            // range paid a full memory latency per record); the index is clamped, not the group read past the range's
+            // end as in the searches above -- a record of the next cell would be met again there and entered twice
+            auto scan_range = [&](uint32_t p0, uint32_t p1) {
+                for (uint32_t p = p0; p < p1; p += 4) {
+                    double4 rc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) rc[u] = recs[p + u < p1 ? p + u : p1 - 1];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (p + u < p1) consider(rc[u]);
+                }
+            };
+            for (int step = 0; step < NBR; ++step) {
+                // own cell first: it fills the list and makes the bound test bite
+                const int nb = step == 0 ? NBR / 2 : (step <= NBR / 2 ? step - 1 : step);
+                const int off[3] = {nb % 3 - 1, (nb / 3) % 3 - 1, nb / 9 - 1};
+                bool inside = true;
+                int x[DIM];
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) {
+                    x[a] = cl[a] + off[a];
+                    inside = inside && x[a] >= 0 && x[a] < ncl;
+                }
+                if (!inside) continue;
+                if (__dsqrt_rn(cell_bound(x, l)) > key[K - 1]) continue;
+                const uint32_t code = morton<DIM>(x);
+                const uint32_t p0 = start[(uint64_t)code << (DIM * l)], p1 = start[((uint64_t)code + 1) << (DIM * l)];
+                if (l == 0 || p1 - p0 <= (uint32_t)kKnnSplit) {
+                    scan_range(p0, p1);
+                    continue;
+                }
+                // A coarse cell with many records (a stray vertex far from the mesh climbs to levels whose cells hold
+                // most of it: 10 strays in 200 000 vertices took the whole launch from 2 to 140 ms): descend instead of
+                // scanning it whole -- a stack of cells, children pushed farthest first so that the nearest is looked at
+                // first and the k-th key prunes the rest.  A cell whose children would not fit is scanned whole.
+                constexpr int NCH = 1 << DIM;
+                uint32_t stk[kKnnStack];
+                int sp = 0;
+                stk[sp++] = pack_cell<DIM>(x, l);
+                while (sp > 0) {
+                    int y[DIM], lv;
+                    unpack_cell<DIM>(stk[--sp], y, lv);
+                    if (__dsqrt_rn(cell_bound(y, lv)) > key[K - 1]) continue;
+                    const uint32_t cc = morton<DIM>(y);
+                    const uint32_t q0 = start[(uint64_t)cc << (DIM * lv)], q1 = start[((uint64_t)cc + 1) << (DIM * lv)];
+                    if (q1 == q0) continue;
+                    if (lv == 0 || q1 - q0 <= (uint32_t)kKnnSplit || sp + NCH > kKnnStack) {
+                        scan_range(q0, q1);
+                        continue;
+                    }
+                    double cb[NCH];
+                    uint32_t cn[NCH];
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        int z[DIM];
+#pragma unroll
+                        for (int a = 0; a < DIM; ++a) z[a] = 2 * y[a] + ((c >> a) & 1);
+                        cb[c] = cell_bound(z, lv - 1);
+                        cn[c] = pack_cell<DIM>(z, lv - 1);
+                    }
+                    for (int i = 0; i < NCH; ++i) {   // farthest first
+                        int mx = -1;
+                        for (int c = 0; c < NCH; ++c)
+                            if (cn[c] != 0xffffffffu && (mx < 0 || cb[c] > cb[mx])) mx = c;
+                        stk[sp++] = cn[mx];
+                        cn[mx] = 0xffffffffu;
+                    }
                 }
             }
             if (ncl == 1) break;
