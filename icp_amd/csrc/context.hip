@@ -92,8 +92,17 @@ extern "C" int icp_ctx_set_stream(icp_ctx *ctx, icp_stream stream) {
     if (next == ctx->stream) return ICP_OK;
     ICP_HIP_CHECK(hipSetDevice(ctx->device));
     if (!ctx->order_ev) ICP_HIP_CHECK(hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
-    ICP_HIP_CHECK(hipEventRecord(ctx->order_ev, ctx->stream));
-    ICP_HIP_CHECK(hipStreamWaitEvent(next, ctx->order_ev, 0));
+    // The previous stream may be gone already (a C host may destroy its stream before handing over the next one):
+    // then the event cannot be recorded on it.  Whatever it had queued is ordered by a device-wide wait instead, and
+    // the context moves to the new stream in every case -- a failed hand-over must not leave it on a dead stream.
+    hipError_t e = hipEventRecord(ctx->order_ev, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(next, ctx->order_ev, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // clear the sticky error of the failed call
+        ctx->stream = next;
+        ICP_HIP_CHECK(hipDeviceSynchronize());
+        return ICP_OK;
+    }
     ctx->stream = next;
     return ICP_OK;
 }

@@ -20,7 +20,10 @@
  *    different stream makes the new stream wait (by an event, without blocking the
  *    host) for everything the context queued on the previous one, so calls issued
  *    under different streams run in issue order.  Use one context per stream for
- *    work that should overlap.
+ *    work that should overlap.  The previous stream should still exist at that call;
+ *    a host that destroys its streams detaches first with icp_ctx_set_stream(ctx, NULL)
+ *    (the null stream).  If the previous stream is gone nevertheless, the call orders
+ *    by a device-wide wait instead and still moves the context to the new stream.
  *  - the library frees nothing it did not allocate.
  */
 #ifndef ICP_HIP_H

@@ -414,3 +414,61 @@ def test_rigid_run_dist_two_ranks_one_gpu(api, n, m, tol, run, world):
     for o in res[1:]:
         assert np.array_equal(res[0]["T"], o["T"]) and np.array_equal(res[0]["hist"][:k], o["hist"][:k])
     assert np.array_equal(np.concatenate([o["idx"] for o in res]), ref["idx"].cpu().numpy())
+
+
+_STREAM_HANDOVER = r"""
+import ctypes, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from icp_amd import _lib
+lib = _lib.load_library()
+hip = ctypes.CDLL("libamdhip64.so")
+rng = np.random.default_rng(3)
+src = torch.from_numpy(rng.standard_normal((5000, 3))).cuda()
+tgt = torch.from_numpy(rng.standard_normal((7000, 3))).cuda()
+ref = torch.cdist(src, tgt).argmin(1).to(torch.int32)
+torch.cuda.synchronize()
+ctx = ctypes.c_void_p()
+assert lib.icp_ctx_create(0, ctypes.byref(ctx)) == 0
+def run(stream):
+    rc = lib.icp_ctx_set_stream(ctx, stream)
+    assert rc == 0, lib.icp_last_error()
+    idx = torch.full((5000,), -7, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    rc = lib.icp_closest(ctx, src.data_ptr(), 5000, tgt.data_ptr(), 7000, 3, 0, idx.data_ptr(), None)
+    assert rc == 0, lib.icp_last_error()
+    assert lib.icp_sync(ctx) == 0
+    assert torch.equal(idx, ref)
+for mode in sys.argv[1:]:
+    a = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(a)) == 0
+    run(a)
+    if mode == "detach":
+        assert lib.icp_ctx_set_stream(ctx, None) == 0      # the documented hand-over: leave the stream first
+    assert hip.hipStreamDestroy(a) == 0
+    b = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(b)) == 0
+    run(b)                                                  # "destroyed": the previous stream is gone at this call
+    run(None)
+    assert hip.hipStreamDestroy(b) == 0
+    c = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(c)) == 0
+    run(c)
+    assert lib.icp_ctx_set_stream(ctx, None) == 0
+    assert hip.hipStreamDestroy(c) == 0
+assert lib.icp_ctx_destroy(ctx) == 0
+print("handover ok")
+"""
+
+
+@pytest.mark.parametrize("mode", ["detach", "destroyed"])
+def test_stream_handover_after_the_old_stream_is_destroyed(mode):
+    """a C host may destroy its stream and hand the context a new one.  With the documented
+    detach step (icp_ctx_set_stream(ctx, NULL) first) and without it -- the previous stream already gone when the
+    next one is set -- the context must end up on the new stream and stay usable.  Run in a child process: what HIP
+    does with a dead stream handle is its own business, and a crash there must read as this test's failure."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _STREAM_HANDOVER % root, mode], capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0 and "handover ok" in out.stdout, out.stdout + out.stderr
