@@ -54,6 +54,9 @@ _SIGNATURES = {
     "icp_shard_apply_err": [c_dp, c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_dp, c_dp, c_dp],
     "icp_column_sums": [c_dp, c_dp, c_i64, c_int, c_dp],
     "icp_bench_grid_query": [c_dp, c_dp, c_i64, c_dp, c_i64, c_int, c_int, c_dp],
+    "icp_rccl_unique_id": [c_dp],
+    "icp_rccl_create": [c_dp, c_dp, c_int, c_int, ctypes.POINTER(ctypes.c_void_p)],
+    "icp_rccl_destroy": [c_dp],
     "nicp_knn": [c_dp, c_dp, c_i64, c_int, c_dp, c_i64, c_int, c_dp, c_dp],
     "nicp_knn_weights": [c_dp, c_dp, c_i64, c_int, c_int, c_dp, c_dp],
     "nicp_graph_create": [c_dp, c_dp, c_dp, c_i64, c_int, c_dp, c_i64, c_int, ctypes.POINTER(ctypes.c_void_p)],
@@ -91,6 +94,8 @@ class CgProfile(ctypes.Structure):
 
 
 NICP_REFERENCE_COMPAT = 1
+ICP_COMM_FORCE = 1
+ICP_RCCL_ID_BYTES = 128
 _RESTYPES = {"icp_last_error": ctypes.c_char_p}
 
 _lib = None
@@ -207,3 +212,44 @@ def get_context(device=None):
         if dev not in _ctxs:
             _ctxs[dev] = Context(dev)
         return _ctxs[dev]
+
+
+class LibraryRccl:
+    """The library's own RCCL communicator (include/icp_hip.h, icp_rccl_*): rank 0 makes the unique id, the host
+    distributes it -- here over torch.distributed, whatever its backend -- and every rank joins collectively.  With
+    world == 1 no process group is needed (one-rank communicator: rehearsals and tests on one GPU)."""
+
+    def __init__(self, ctx=None, rank=None, world=None, group=None):
+        self.ctx = ctx or get_context()
+        torch = self.ctx.torch
+        lib = self.ctx.lib
+        if world is None or world > 1:
+            import torch.distributed as dist
+            rank = dist.get_rank(group) if rank is None else rank
+            world = dist.get_world_size(group) if world is None else world
+        self.rank, self.world = int(rank or 0), int(world)
+        ident = (ctypes.c_char * ICP_RCCL_ID_BYTES)()
+        if self.rank == 0:
+            check(lib.icp_rccl_unique_id(ident))
+        if self.world > 1:
+            import torch.distributed as dist
+            dev = "cuda:%d" % self.ctx.device if dist.get_backend(group) == "nccl" else "cpu"
+            t = torch.frombuffer(bytearray(bytes(ident)), dtype=torch.uint8).to(dev)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = (ctypes.c_char * ICP_RCCL_ID_BYTES).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+        h = ctypes.c_void_p()
+        torch.cuda.synchronize(self.ctx.device)
+        check(lib.icp_rccl_create(self.ctx.handle, ident, self.rank, self.world, ctypes.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.torch.cuda.synchronize(self.ctx.device)
+            self.ctx.lib.icp_rccl_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -136,6 +136,11 @@ bool grid_worthwhile(int64_t n, int64_t m, unsigned flags);
 // exact k nearest (k = 6 or 8) by the key fl(sqrt(d2)), ties to the lower index, through a built grid
 int grid_knn(icp_ctx *ctx, const GridBuild &gb, const double *q, int64_t nq, int k, int32_t *idx_out, double *dist_out);
 
+// library-side RCCL (rccl.hip): collectives enqueued on a stream by the library itself
+int rccl_allreduce_sum(icp_rccl *rc, double *buf, int count, hipStream_t stream);
+int rccl_exchange(icp_rccl *rc, const double *send_buf, const int64_t *send_counts, double *recv_buf, const int64_t *recv_counts,
+                  int width, hipStream_t stream);
+
 // 64-bit shuffle helpers (wave = 64 lanes)
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
     int lo = __double2loint(v), hi = __double2hiint(v);

@@ -850,8 +850,10 @@ __global__ void dist_unsort_idx_kernel(const int32_t *__restrict__ b0, const int
     }
 }
 
-static int comm_allreduce(const icp_comm *cm, int count) {
-    if (!cm || cm->world <= 1) return ICP_OK;
+static bool comm_active(const icp_comm *cm) { return cm && (cm->world > 1 || (cm->flags & ICP_COMM_FORCE)); }
+static int comm_allreduce(icp_ctx *ctx, const icp_comm *cm, int count) {
+    if (!comm_active(cm)) return ICP_OK;
+    if (cm->rccl) return rccl_allreduce_sum(cm->rccl, cm->reduce_buf_dev, count, ctx->stream);  // on the stream: no host code
     if (int rc = cm->allreduce_sum(cm->user, count)) {
         set_error("icp_rigid_run_dist: the all-reduce callback failed (%d)", rc);
         return ICP_ERR_COMM;
@@ -871,7 +873,7 @@ namespace icp {
 static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim, double tol,
                       int max_iter, int use_tol, unsigned flags, double *T_out_dev, double *err_hist_dev,
                       int32_t *iters_out_dev, int32_t *idx_out, const icp_comm *comm) {
-    const int world = comm ? comm->world : 1;
+    const bool dist = comm_active(comm);  // every sum goes through the (all-)reduce buffer
     if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
     if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
     if (int rc = ensure(ctx, ctx->work_d, (size_t)n * sizeof(int32_t) * 2)) return rc;
@@ -909,7 +911,7 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
     }
     RigidState *st = (RigidState *)ctx->small.ptr;
     // a single rank needs no buffer from the caller: the 17 doubles live behind the RigidState block
-    double *buf = world > 1 ? comm->reduce_buf_dev : (double *)ctx->small.ptr + 128;
+    double *buf = dist ? comm->reduce_buf_dev : (double *)ctx->small.ptr + 128;
     static_assert(sizeof(RigidState) <= 128 * sizeof(double), "RigidState overlaps the local reduce buffer");
     double *part = (double *)ctx->partials.ptr;
     int32_t *ib[2] = {(int32_t *)ctx->work_d.ptr, (int32_t *)ctx->work_d.ptr + n};
@@ -922,7 +924,7 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
         else hipLaunchKernelGGL(column_sums_kernel<2>, dim3(nb), dim3(RB), 0, s, src, n, part);
         hipLaunchKernelGGL(dist_pack_means_kernel, dim3(1), dim3(RB), 0, s, (const double *)part, nb, buf);
         ICP_HIP_CHECK(hipGetLastError());
-        if (int rc = comm_allreduce(comm, 4)) return rc;
+        if (int rc = comm_allreduce(ctx, comm, 4)) return rc;
         hipLaunchKernelGGL(dist_means_kernel, dim3(1), dim3(64), 0, s, (const double *)buf, dim, st);
     }
     if (int rc = column_sums(ctx, tgt, m, dim, st->ct, 1)) return rc;
@@ -942,13 +944,13 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
             return rc;
         int nb = 0;
         if (int rc = shard_sums(ctx, src, tgt_rows, idx, n, dim, st->cs, st->ct, st->sums, done, &nb)) return rc;
-        if (world == 1 && fused) {
+        if (!dist && fused) {
             if (dim == 3) hipLaunchKernelGGL(fused_solve_kernel<3>, dim3(1), dim3(RB), 0, s, (const double *)part, nb, (const double *)err_part, nerr, st, first, tol, use_tol, err_hist_dev);
             else hipLaunchKernelGGL(fused_solve_kernel<2>, dim3(1), dim3(RB), 0, s, (const double *)part, nb, (const double *)err_part, nerr, st, first, tol, use_tol, err_hist_dev);
         } else {
             hipLaunchKernelGGL(dist_pack_kernel, dim3(1), dim3(RB), 0, s, (const double *)part, nb, (const RigidState *)st, first, buf, (const double *)err_part, nerr);
             ICP_HIP_CHECK(hipGetLastError());
-            if (int rc = comm_allreduce(comm, kSumSlots + 1)) return rc;
+            if (int rc = comm_allreduce(ctx, comm, kSumSlots + 1)) return rc;
             if (dim == 3) hipLaunchKernelGGL(dist_solve_kernel<3>, dim3(1), dim3(64), 0, s, (const double *)buf, st, first, tol, use_tol, err_hist_dev);
             else hipLaunchKernelGGL(dist_solve_kernel<2>, dim3(1), dim3(64), 0, s, (const double *)buf, st, first, tol, use_tol, err_hist_dev);
         }
@@ -961,7 +963,7 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
     }
     hipLaunchKernelGGL(dist_last_pack_kernel, dim3(1), dim3(1), 0, s, (const RigidState *)st, buf);
     ICP_HIP_CHECK(hipGetLastError());
-    if (int rc = comm_allreduce(comm, 1)) return rc;
+    if (int rc = comm_allreduce(ctx, comm, 1)) return rc;
     hipLaunchKernelGGL(dist_last_step_kernel, dim3(1), dim3(1), 0, s, (const double *)buf, st, err_hist_dev);
     if (idx_out)
         hipLaunchKernelGGL(dist_unsort_idx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int32_t *)ib[0],
@@ -997,7 +999,7 @@ extern "C" int icp_rigid_run_dist(icp_ctx *ctx, const double *src, int64_t n, co
     ICP_REQUIRE(n > 0 && m > 0 && m < 0x7fffffff, "need n > 0 (every rank holds rows) and 0 < m < 2^31");
     ICP_REQUIRE(max_iter > 0, "run = 0 leaves R undefined (icp_3d.py:118-120)");
     ICP_REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, "bad rank / world");
-    ICP_REQUIRE(comm->world == 1 || (comm->reduce_buf_dev && comm->allreduce_sum), "comm buffer / callback missing");
+    ICP_REQUIRE(!icp::comm_active(comm) || (comm->reduce_buf_dev && (comm->allreduce_sum || comm->rccl)), "comm buffer / callback missing");
     return rigid_loop(ctx, src, n, tgt, m, dim, tol, max_iter, use_tol, flags, T_out_dev, err_hist_dev, iters_out_dev, idx_out, comm);
 }
 

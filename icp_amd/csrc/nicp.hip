@@ -2583,15 +2583,19 @@ static int apply_J(icp_ctx *ctx, nicp_graph *g, Work &w, const double *P, const 
 // buffer every reduction lands in before the (optional) all-reduce over ranks.
 struct Par {
     const nicp_comm *comm = nullptr;
+    icp_ctx *ctx = nullptr;
     int64_t nown = 0;
     double *tot = nullptr;
     const double *row_mask = nullptr;
-    bool sharded() const { return comm && comm->world > 1; }
+    bool sharded() const { return comm && (comm->world > 1 || (comm->flags & ICP_COMM_FORCE)); }
+    // collectives issued by the library itself on the context's stream (rccl.hip): nothing on the host per collective
+    bool native() const { return sharded() && comm->rccl != nullptr; }
     int rank() const { return comm ? comm->rank : 0; }
 };
 
-static Par par_single(const nicp_graph *g, Work &w) {
+static Par par_single(icp_ctx *ctx, const nicp_graph *g, Work &w) {
     Par p;
+    p.ctx = ctx;
     p.nown = g->n;
     p.tot = w.tot;
     return p;
@@ -2599,6 +2603,7 @@ static Par par_single(const nicp_graph *g, Work &w) {
 
 static int allreduce(const Par &par, int count) {
     if (!par.sharded()) return ICP_OK;
+    if (par.native()) return rccl_allreduce_sum(par.comm->rccl, par.tot, count, par.ctx->stream);
     if (int rc = par.comm->allreduce_sum(par.comm->user, count)) {
         set_error("nicp_solve_dist: the all-reduce callback failed (%d)", rc);
         return ICP_ERR_COMM;
@@ -2615,7 +2620,10 @@ static int exchange(icp_ctx *ctx, const nicp_graph *g, const Work &w, const Par 
         hipLaunchKernelGGL(pack_kernel, dim3(grid_for(cm->n_send * S, 1 << 30)), dim3(NB), 0, ctx->stream, (const double *)vec,
                            cm->send_idx_dev, cm->n_send, S, cm->send_buf_dev, w.st);
     ICP_HIP_CHECK(hipGetLastError());
-    if (int rc = cm->exchange(cm->user)) {
+    if (par.native()) {
+        if (int rc = rccl_exchange(cm->rccl, cm->send_buf_dev, cm->send_counts_host, cm->recv_buf_dev, cm->recv_counts_host, S, ctx->stream))
+            return rc;
+    } else if (int rc = cm->exchange(cm->user)) {
         set_error("nicp_solve_dist: the halo-exchange callback failed (%d)", rc);
         return ICP_ERR_COMM;
     }
@@ -3067,7 +3075,7 @@ extern "C" int nicp_jtvp(icp_ctx *ctx, nicp_graph *g, const double *P, const dou
         if (int rc = weight_rows(ctx, g, w, c3_host, u_in, w.y)) return rc;
         u_in = w.y;
     }
-    return apply_JT(ctx, g, w, par_single(g, w), P, v, c3_host, flags & 1u, u_in, nullptr, nullptr, 0.0, g_out, false);
+    return apply_JT(ctx, g, w, par_single(ctx, g, w), P, v, c3_host, flags & 1u, u_in, nullptr, nullptr, 0.0, g_out, false);
 }
 
 // Levenberg-Marquardt with two-level preconditioned CG; par says whether this is the whole mesh
@@ -3216,6 +3224,11 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
     if (const char *e = getenv("ICP_NICP_PREC32")) prec32 = atoi(e) != 0;
     bool use_graph = !par.sharded() && d.n >= 1024;
     if (const char *e = getenv("ICP_NICP_GRAPH")) use_graph = !par.sharded() && atoi(e) != 0;
+    // Sharded solve with library-side RCCL: nothing of an iteration runs on the host any more, so the chunk can be
+    // captured like the single-GPU one.  Opt-in (ICP_NICP_GRAPH_DIST=1): capturing RCCL's launches has only been run on
+    // a one-rank communicator (tests/test_gpu_nicp_dist.py), no multi-GPU node was available to this build.
+    if (par.native())
+        if (const char *e = getenv("ICP_NICP_GRAPH_DIST")) use_graph = atoi(e) != 0 && d.n >= 1024;
     if (use_graph) {
         if (!ctx->side && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) use_graph = false;
         if (use_graph && !ctx->side_ev && hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming) != hipSuccess) use_graph = false;
@@ -3572,7 +3585,7 @@ extern "C" int nicp_solve(icp_ctx *ctx, nicp_graph *g, double *P_inout, const do
                           nicp_solve_stats *stats_out) {
     NICP_ARGS(ctx, g);
     ICP_REQUIRE(P_inout && v && nn && c3_host, "null pointer");
-    return solve_impl(ctx, g, w, par_single(g, w), P_inout, v, nn, c3_host, flags, opts_in, stats_out);
+    return solve_impl(ctx, g, w, par_single(ctx, g, w), P_inout, v, nn, c3_host, flags, opts_in, stats_out);
 }
 
 extern "C" int nicp_profile_cg(icp_ctx *ctx, nicp_graph *g, const double *P, const double *v, const double *nn,
@@ -3586,7 +3599,7 @@ extern "C" int nicp_profile_cg(icp_ctx *ctx, nicp_graph *g, const double *P, con
     int rc = hipMemcpyAsync(Pc, P, d.np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? ICP_OK : ICP_ERR_HIP;
     std::memset(out_host, 0, sizeof(*out_host));
     out_host->iterations = iterations;
-    if (!rc) rc = solve_impl(ctx, g, w, par_single(g, w), Pc, v, nn, c3_host, flags, nullptr, nullptr, out_host);
+    if (!rc) rc = solve_impl(ctx, g, w, par_single(ctx, g, w), Pc, v, nn, c3_host, flags, nullptr, nullptr, out_host);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(Pc);
     return rc;
@@ -3607,15 +3620,17 @@ extern "C" int nicp_solve_dist(icp_ctx *ctx, nicp_graph *g, double *P_inout, con
     }
     Par par;
     par.comm = comm;
+    par.ctx = ctx;
     par.nown = comm->n_owned;
     par.tot = w.tot;
-    if (comm->world > 1) {
-        ICP_REQUIRE(comm->reduce_buf_dev && comm->row_mask_dev && comm->allreduce_sum && comm->exchange, "comm buffers / callbacks missing");
+    if (par.sharded()) {
+        ICP_REQUIRE(comm->reduce_buf_dev && comm->row_mask_dev, "comm buffers missing");
+        ICP_REQUIRE(comm->rccl ? (comm->send_counts_host && comm->recv_counts_host) : (comm->allreduce_sum && comm->exchange),
+                    "callbacks missing (or, with rccl, the per-rank send / receive counts)");
         par.tot = comm->reduce_buf_dev;
         par.row_mask = comm->row_mask_dev;
-    } else {
-        ICP_REQUIRE(comm->n_owned == g->n, "a single rank owns every local vertex");
     }
+    if (comm->world == 1) ICP_REQUIRE(comm->n_owned == g->n, "a single rank owns every local vertex");
     return solve_impl(ctx, g, w, par, P_inout, v, nn, c3_host, flags, opts_in, stats_out);
 }
 

@@ -232,16 +232,20 @@ def sharded_icp(ops, comm, src_shard, tgt, tol, run, use_tol=True):
 class IcpComm(ctypes.Structure):
     """icp_comm of include/icp_hip.h"""
     _fields_ = [("rank", ctypes.c_int), ("world", ctypes.c_int), ("reduce_buf_dev", ctypes.c_void_p),
-                ("user", ctypes.c_void_p), ("allreduce_sum", ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int))]
+                ("user", ctypes.c_void_p), ("allreduce_sum", ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)),
+                ("rccl", ctypes.c_void_p), ("flags", ctypes.c_uint)]
 
 
 class RigidComm:
     """The all-reduce callback of icp_comm over torch.distributed.  backend "nccl" (= RCCL): the collective runs on
     the device buffer, ordered on torch's current stream = the stream the context launches on, no host
     synchronisation.  Any other backend (gloo: ranks sharing one GPU in rehearsals and tests) stages through the host.
-    `device="cpu"` exercises the protocol without a GPU (tests/test_dist_cpu.py)."""
+    `device="cpu"` exercises the protocol without a GPU (tests/test_dist_cpu.py).
+    `rccl`: a _lib.LibraryRccl -- the library then issues the collectives itself on the context's stream and this
+    object's callback is never called (`calls` stays empty).  `force`: ICP_COMM_FORCE, every collective is issued even
+    with one rank."""
 
-    def __init__(self, device, group=None, rank=None, world=None):
+    def __init__(self, device, group=None, rank=None, world=None, rccl=None, force=False):
         import torch
         self.torch, self.group = torch, group
         self.dist = None
@@ -256,7 +260,9 @@ class RigidComm:
         self.calls = []          # doubles per collective, in call order
         self.error = None
         self._cb = IcpComm._fields_[4][1](self._allreduce)
-        self.struct = IcpComm(self.rank, self.world, ctypes.c_void_p(self.reduce_buf.data_ptr()), None, self._cb)
+        self.rccl = rccl
+        self.struct = IcpComm(self.rank, self.world, ctypes.c_void_p(self.reduce_buf.data_ptr()), None, self._cb,
+                              rccl.handle if rccl is not None else None, _lib.ICP_COMM_FORCE if force else 0)
 
     def allreduce(self, count):
         self.calls.append(count)

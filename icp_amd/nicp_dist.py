@@ -170,7 +170,9 @@ class NicpComm(ctypes.Structure):
                 ("send_buf_dev", ctypes.c_void_p), ("recv_buf_dev", ctypes.c_void_p), ("row_mask_dev", ctypes.c_void_p),
                 ("user", ctypes.c_void_p),
                 ("allreduce_sum", ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)),
-                ("exchange", ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p))]
+                ("exchange", ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)),
+                ("rccl", ctypes.c_void_p), ("send_counts_host", ctypes.c_void_p), ("recv_counts_host", ctypes.c_void_p),
+                ("flags", ctypes.c_uint)]
 
 
 class TorchComm:
@@ -180,9 +182,11 @@ class TorchComm:
     after the work queued on torch's current stream, which is the stream the context
     launches on -- no host synchronisation.  Any other backend (gloo: CPU tests, or
     several ranks sharing one GPU) stages through host memory.
-    `device` may be "cpu" to exercise the exchange logic without a GPU."""
+    `device` may be "cpu" to exercise the exchange logic without a GPU.
+    `rccl`: a _lib.LibraryRccl -- the library issues both collectives itself over RCCL on the context's stream and the
+    callbacks are never called; `force`: ICP_COMM_FORCE (every collective issued even with one rank)."""
 
-    def __init__(self, shard, device, group=None):
+    def __init__(self, shard, device, group=None, rccl=None, force=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -198,15 +202,20 @@ class TorchComm:
         self.row_mask = torch.from_numpy(shard.row_mask).to(device)
         self.in_splits = [int(c) * S for c in shard.send_counts]
         self.out_splits = [int(c) * S for c in shard.recv_counts]
-        self.native = self.world > 1 and dist.get_backend(group) == "nccl" and self.reduce_buf.is_cuda
+        self.native = self.world > 1 and dist.is_initialized() and dist.get_backend(group) == "nccl" and self.reduce_buf.is_cuda
         self.calls = {"allreduce": 0, "exchange": 0}
         self.error = None
         self._cb_ar = NicpComm._fields_[10][1](self._allreduce)
         self._cb_ex = NicpComm._fields_[11][1](self._exchange)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
+        self.rccl = rccl
+        self._send_counts = np.ascontiguousarray(shard.send_counts, dtype=np.int64)
+        self._recv_counts = np.ascontiguousarray(shard.recv_counts, dtype=np.int64)
         self.struct = NicpComm(self.rank, self.world, shard.n_owned, p(self.reduce_buf), p(self.send_idx),
                                len(shard.send_idx), p(self.send_buf), p(self.recv_buf), p(self.row_mask), None,
-                               self._cb_ar, self._cb_ex)
+                               self._cb_ar, self._cb_ex, rccl.handle if rccl is not None else None,
+                               self._send_counts.ctypes.data, self._recv_counts.ctypes.data,
+                               _lib.ICP_COMM_FORCE if force else 0)
 
     # plain methods (also used directly by the CPU tests)
     def allreduce(self, count):
@@ -266,7 +275,8 @@ class TorchComm:
 class ShardedNICP:
     """Rank-local state of a sharded NICP run over the C-ABI."""
 
-    def __init__(self, source, nbr, wt, edges, target, P0=None, world=None, rank=None, owner=None, ctx=None, group=None):
+    def __init__(self, source, nbr, wt, edges, target, P0=None, world=None, rank=None, owner=None, ctx=None, group=None,
+                 rccl=None, force=False):
         import torch.distributed as dist
         from . import nicp as _nicp
         self.ctx = ctx or _lib.get_context()
@@ -281,7 +291,7 @@ class ShardedNICP:
         self.shard = sh = shards[rank]
         self.shards_meta = [(s.n_owned, s.n_halo) for s in shards]
         dev = "cuda:%d" % ctx.device
-        self.comm = TorchComm(sh, dev, group)
+        self.comm = TorchComm(sh, dev, group, rccl=rccl, force=force)
         self.v = ctx.to_dev(sh.localize(source, self.dim))
         self.weights = _nicp.SparseWeights(sh.nbr, sh.wt, self.dim, ctx)
         self.graph, self.ne = self.weights.graph(sh.edges if len(sh.edges) else None)

@@ -176,12 +176,34 @@ int icp_column_sums(icp_ctx *ctx, const double *a, int64_t n, int dim, double *o
  * decides -- decisions are taken on the device from all-reduced values, so the host never reads anything back inside
  * the loop.  src is the rank's shard [n_local, dim]; T / err_hist / iters are identical on all ranks; idx_out
  * [n_local] are the shard's correspondences of the last executed iteration.  world = 1 runs without callbacks and
- * returns what icp_rigid_run returns, bit for bit.  No counterpart in the reference (single process). */
+ * returns what icp_rigid_run returns, bit for bit.  No counterpart in the reference (single process).
+ *
+ * Library-side RCCL (icp_comm.rccl / nicp_comm.rccl).  The north_star's "RCCL over xGMI all-reduces the covariance /
+ * CG partial sums": rank 0 calls icp_rccl_unique_id, the host distributes the ICP_RCCL_ID_BYTES bytes to every rank by
+ * whatever means it has (torch.distributed broadcast, MPI_Bcast, a file), every rank calls icp_rccl_create with the
+ * same id -- collectively, one process per GPU, with its context's device current -- and hands the handle over in the
+ * comm structs.  The library then enqueues ncclAllReduce / grouped ncclSend + ncclRecv on the context's stream, ordered
+ * like kernel launches: zero host callbacks per iteration.  librccl is opened at run time (no link-time dependency);
+ * without it icp_rccl_* return ICP_ERR_UNSUPPORTED and the callbacks remain.  Destroy the handle (collectively) after the
+ * last call that used it has completed. */
+#define ICP_RCCL_ID_BYTES 128
+typedef struct icp_rccl icp_rccl; /* the library's own RCCL communicator */
+int icp_rccl_unique_id(void *id_out_host);
+int icp_rccl_create(icp_ctx *ctx, const void *id_host, int rank, int world, icp_rccl **out);
+int icp_rccl_destroy(icp_rccl *r);
+
+enum {
+    ICP_COMM_FORCE = 1u /* issue every collective even when world == 1 (rehearsals and tests on one GPU: the whole
+                           sharded code path runs, the sums over "ranks" are sums over one rank) */
+};
 typedef struct icp_comm {
     int rank, world;
     double *reduce_buf_dev; /* >= 32 doubles (device); allreduce_sum sums its first `count` entries over ranks in place */
     void *user;
     int (*allreduce_sum)(void *user, int count);
+    icp_rccl *rccl;         /* non-NULL: the library issues ncclAllReduce on the context's stream itself and never calls
+                               allreduce_sum (which may then be NULL): no host code runs per collective */
+    unsigned flags;         /* ICP_COMM_FORCE */
 } icp_comm;
 int icp_rigid_run_dist(icp_ctx *ctx, const double *src_local, int64_t n_local, const double *tgt, int64_t m, int dim,
                        double tol, int max_iter, int use_tol, unsigned flags, double *T_out_dev, double *err_hist_dev,
@@ -331,6 +353,11 @@ typedef struct nicp_comm {
     void *user;
     int (*allreduce_sum)(void *user, int count);
     int (*exchange)(void *user);
+    icp_rccl *rccl;                 /* non-NULL: both collectives are issued by the library over RCCL (see icp_rccl_create);
+                                       the callbacks are not called and may be NULL */
+    const int64_t *send_counts_host; /* [world] with rccl: vertices sent to every rank (send_idx_dev is grouped that way) */
+    const int64_t *recv_counts_host; /* [world] with rccl: halo vertices received from every rank (local halo order is by owner rank) */
+    unsigned flags;                 /* ICP_COMM_FORCE */
 } nicp_comm;
 
 /* nicp_solve on one rank of a sharded mesh: same algorithm, every sum completed by allreduce_sum
