@@ -140,12 +140,100 @@ def nicp_c3(ctx, compat):
                            ((1, "ftol"), (2, "xtol"), (3, "ftol+xtol"), (4, "gtol"), (5, "limit"))}}
 
 
+def _max_over_ranks(dt, share_gpu):
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.cpu()[0])
+
+
+def leg_c4(args, ctx, comm, lib_rccl, world, rank, barrier):
+    """BASELINE config C4: rigid ICP 2^24 x 2^24, source rows sharded, target replicated, 10 iterations through
+    icp_rigid_run_dist; every rank checks a sample of its shard's correspondences against the full scan."""
+    import torch
+    import torch.distributed as dist
+    from icp_amd import rigid
+    from icp_amd.dist import RigidComm, rigid_icp_dist, shard_bounds
+    n4, K4 = args.c4_n, 10
+    src4, tgt4 = make_cloud(n4, seed=2)
+    lo, hi = shard_bounds(n4, world, rank)
+    s_d, t_d = ctx.to_dev(src4[lo:hi]), ctx.to_dev(tgt4)
+    del src4, tgt4
+    cm = RigidComm("cuda:%d" % ctx.device, rccl=lib_rccl)
+    run4 = lambda k, want: rigid_icp_dist(s_d, t_d, 0.0, k, use_tol=False, want_idx=want, comm=cm, ctx=ctx)
+    run4(2, False)                                         # warm (scratch buffers, communicator)
+    barrier()
+    t0 = time.perf_counter()
+    res = run4(K4, True)
+    barrier()
+    dt = _max_over_ranks(time.perf_counter() - t0, args.share_gpu)
+    # correspondences of the last iteration on a sample of this rank's rows vs the brute-force scan of the same positions
+    prev = run4(K4 - 1, False)["T"]
+    n_loc = s_d.shape[0]
+    take = torch.from_numpy(np.random.default_rng(100 + rank).choice(n_loc, size=min(n_loc, 1 << 15), replace=False)).to(s_d.device)
+    ss = rigid.apply_transform(s_d[take].contiguous(), prev[:3, :3].contiguous(), prev[3, :3].contiguous(), ctx=ctx)
+    ok = torch.equal(rigid.closest_indices(ss, t_d, force_brute=True, ctx=ctx), res["idx"][take])
+    flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return {"workload": "C4: rigid ICP %d x %d fp64 points (seed 2), source rows sharded over %d ranks, target replicated, "
+                        "%d iterations in one icp_rigid_run_dist call incl. grid build + Morton sort" % (n4, n4, world, K4),
+            "seconds": dt, "ms_per_step": dt / K4 * 1e3, "queries_per_s": n4 * K4 / dt, "icp_iters_per_s": K4 / dt,
+            "rows_per_rank": int(n_loc), "collectives_per_iteration": 1, "doubles_per_collective": 17,
+            "host_callbacks": len(cm.calls), "last_err": float(res["err_hist"].cpu()[K4 - 1]),
+            "check_idx_equal_bruteforce": bool(float(flag.cpu()[0]) == 1.0), "n_checked_per_rank": int(take.numel()),
+            "check": "sample of each rank's last-iteration correspondences vs an ICP_FORCE_BRUTE Match of the same moved rows "
+                     "against all %d targets" % n4}
+
+
+def leg_c5(args, ctx, comm, lib_rccl, world, rank, barrier):
+    """BASELINE config C5: NICP on the 200 704-vertex mesh, vertices sharded along the Morton curve with halos, through
+    nicp_solve_dist.  A bounded piece of the first outer iteration is timed (whole self-consistent schedules take
+    minutes): Deform -> Match -> 2 LM steps of at most 300 CG iterations."""
+    import torch
+    from icp_amd import nicp, nicp_dist
+    sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+    from nicp_bench import make_grid_mesh
+    v, edges, tgt = make_grid_mesh(args.c5_nx, args.c5_nx, seed=7)
+    w = nicp.knn_weights(v, ctx)
+    nbr, wt = w.nbr.cpu().numpy(), w.wt.cpu().numpy()
+    sh = nicp_dist.ShardedNICP(v, nbr, wt, edges, tgt, world=world, rank=rank, ctx=ctx, rccl=lib_rccl)
+    c = (0.1, 1000.0, 100.0)
+    opts = dict(max_lm_iters=2, max_cg_iters=300, cg_tol=1e-6)
+    nn = sh.match()
+    keep = sh.P.clone()
+    sh.solve(nn, c, dict(max_lm_iters=1, max_cg_iters=20, cg_tol=1e-6))      # warm (workspace, communicator)
+    sh.P.copy_(keep)
+    calls0 = dict(sh.comm.calls)
+    barrier()
+    t0 = time.perf_counter()
+    nn = sh.match()
+    torch.cuda.synchronize()
+    t_match = time.perf_counter() - t0
+    st = sh.solve(nn, c, opts)
+    barrier()
+    dt = _max_over_ranks(time.perf_counter() - t0, args.share_gpu)
+    cg = max(st["cg_iters"], 1)
+    cb = sum(sh.comm.calls.values()) - sum(calls0.values())
+    return {"workload": "C5: NICP %dx%d grid mesh (%d vertices, %d edges), vertices sharded over %d ranks along a Morton curve, "
+                        "halo = KNN lists + edges; first outer iteration bounded to 2 LM steps of <= 300 CG iterations, "
+                        "self-consistent mode (the reference's quirk Q5 does not shard)" % (args.c5_nx, args.c5_nx, len(v), len(edges), world),
+            "seconds": dt, "match_seconds": t_match, "lm_iters": st["lm_iters"], "cg_iters": st["cg_iters"],
+            "cg_iters_per_s": st["cg_iters"] / dt, "us_per_cg_iter": (dt - t_match) / cg * 1e6,
+            "outer_iters_per_s_bounded": 1.0 / dt, "err0": st["err0"], "err": st["err"],
+            "owned_vertices": int(sh.shard.n_owned), "halo_vertices": int(sh.shard.n_halo),
+            "halo_fraction": sh.shard.n_halo / max(sh.shard.n_owned, 1),
+            "collectives_per_cg_iteration": 3, "collectives": "2 all-reduces of <= 68 doubles + 1 halo exchange of the search direction",
+            "host_callbacks_per_cg_iteration": cb / cg, "graph_launches": st["graph_launches"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)   # C2: 30 iterations
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1 << 20, help="source AND target points (default 2^20)")
+    ap.add_argument("--n", "--points", dest="n", type=int, default=1 << 20,
+                    help="source AND target points (default 2^20); under torch.distributed.run spell it --points (its own parser trips over --n)")
     ap.add_argument("--repeats", type=int, default=5, help="further timed calls of K steps after the first (extra.repeats)")
     ap.add_argument("--cpu-sample", type=int, default=262144, help="queries the CPU baseline matches (about 15-20 s on 16 threads)")
     ap.add_argument("--numpy-queries", type=int, default=64, help="queries of the numpy Closest restatement (0: skip)")
@@ -159,6 +247,15 @@ def main():
                          "call back every collective (measures the host cost of the multi-GPU path on one GPU)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses GPU 0 and the all-reduce goes over gloo")
+    ap.add_argument("--comm", choices=("rccl", "callback"), default="rccl",
+                    help="N > 1 (and --rehearse-comm): who issues the collectives -- the library itself over its own RCCL "
+                         "communicator on the context's stream (default; include/icp_hip.h icp_rccl_create), or the host "
+                         "callback over torch.distributed.  --share-gpu always uses the callback (RCCL refuses two ranks on one GPU)")
+    ap.add_argument("--no-multi-legs", action="store_true", help="N > 1: skip extra.c4 / extra.c5")
+    ap.add_argument("--c4-n", type=int, default=1 << 24, help="N > 1: points per cloud of the extra.c4 leg (BASELINE config C4: 2^24)")
+    ap.add_argument("--c5-nx", type=int, default=448, help="N > 1: grid side of the extra.c5 mesh (448 x 448 = 200 704 vertices)")
+    ap.add_argument("--legs-deadline", type=float, default=300.0,
+                    help="N > 1: seconds the extra.c4 / extra.c5 legs may take before the line is printed without them")
     args = ap.parse_args()
 
     import torch
@@ -196,16 +293,26 @@ def main():
     K, W = args.steps, args.warmup
     src_d, tgt_d = ctx.to_dev(src[lo:hi]), ctx.to_dev(tgt)
     n_loc = src_d.shape[0]
-    comm = RigidComm("cuda:%d" % local_rank) if distributed else None
+    use_lib_rccl = args.comm == "rccl" and not args.share_gpu
+    lib_rccl = None
+    comm = None
+    if distributed:
+        if use_lib_rccl:
+            lib_rccl = _lib.LibraryRccl(ctx, rank=rank, world=world)       # the library's own communicator (id broadcast over torch)
+        comm = RigidComm("cuda:%d" % local_rank, rccl=lib_rccl)
     if args.rehearse_comm and not distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-        dist.all_reduce(torch.zeros(17, dtype=torch.float64, device="cuda"))
-        comm = RigidComm("cuda:%d" % local_rank)
-        comm.world, comm.native = 2, True        # Python side: really all-reduce (over the one-rank RCCL group)
-        comm.struct.world = 2                    # library side: call back for every collective
+        if use_lib_rccl:
+            lib_rccl = _lib.LibraryRccl(ctx, rank=0, world=1)              # one-rank communicator, every collective really issued
+            comm = RigidComm("cuda:%d" % local_rank, world=1, rccl=lib_rccl, force=True)
+        else:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            dist.all_reduce(torch.zeros(17, dtype=torch.float64, device="cuda"))
+            comm = RigidComm("cuda:%d" % local_rank)
+            comm.world, comm.native = 2, True        # Python side: really all-reduce (over the one-rank RCCL group)
+            comm.struct.world = 2                    # library side: call back for every collective
 
     def barrier():
         if distributed:
@@ -301,8 +408,11 @@ def main():
     else:
         gbytes = 24.0 * n_loc + 4.0 * n_loc + 32.0 * n + 4.0 * (1 << 21)   # queries + idx out + 32-B target records + cell-start array
         achieved = gbytes / t_kernel / 1e9
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "latency: vector-instruction issue + L1 address path (not hbm, not mfma; counters below)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac_compulsory": compulsory / t_kernel / 1e9 / HBM_PEAK_GBS,
+                "compulsory_bytes": compulsory,
                 "kernel": "grid search = grid_query_kernel<3,false,256,4> + grid_defer_kernel<3,false>", "kernel_ms": t_kernel * 1e3,
                 "kernel_ms_parts": {"grid_query_kernel": t_lane * 1e3, "grid_defer_kernel": t_defer * 1e3},
                 "note": "exact grid search (two launches: per-lane pass, then one wave per deferred query): algorithmic "
@@ -311,11 +421,19 @@ def main():
                         "path (TA busy 66-82%%) and fp64 VALU (~50%%) on gathers from the L2/MALL-resident sorted target, "
                         "not by HBM, so the HBM fraction is low by construction; equivalent brute-force rate = %.3g "
                         "pair-evaluations/s" % (gbytes / 1e6, pairs / t_kernel)}
-        try:   # HBM-side bytes per launch from the committed PMC passes (profiles/r2_pmc_grid.txt); valid for the default size only
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
-            if n == (1 << 20) and world == 1:
+        try:   # HBM-side bytes per launch and the busy fractions from the committed PMC passes; valid for the default size only
+            tr = None
+            for name in ("r3_traffic.json", "r2_traffic.json"):
+                path = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(path):
+                    tr = json.load(open(path))
+                    break
+            if tr is not None and n == (1 << 20) and world == 1:
                 roof["traffic"] = tr["traffic_bytes"]
                 roof["traffic_source"] = tr["source"]
+                for k in ("valu_busy", "ta_busy", "wait_frac", "l2_hit"):
+                    if k in tr:
+                        roof[k] = tr[k]
         except Exception:
             pass
         if brute_roof is not None:
@@ -345,7 +463,7 @@ def main():
         except Exception as e:      # the rigid line must survive an NICP failure
             extra["nicp_c3"] = {"error": repr(e)}
 
-    if rank == 0:
+    def build_line():
         cfg = {"workload": "%s: rigid ICP, %d source x %d target fp64 points (N(0,1)^3, seed 1, Rz(0.3)+shift, permuted), "
                            "source rows sharded over %d GPU(s), target replicated" % (
                                "C2" if n == (1 << 20) else ("C4-size" if n == (1 << 24) else "custom"), n, n, world),
@@ -353,8 +471,13 @@ def main():
                "search": "brute-force scan" if args.brute else "exact multi-resolution grid (bit-identical to the scan)",
                "timed_region": "one icp_rigid_run%s call of K iterations incl. grid build + Morton sort" % (
                    "_dist" if (distributed or comm is not None) else "") + (
-                   " (REHEARSAL: one rank, every collective really issued on a one-rank RCCL group)" if args.rehearse_comm else ""),
-               "last_err": err_last, "check": check}
+                   " (REHEARSAL: one rank, every collective really issued on a one-rank RCCL communicator)" if args.rehearse_comm else ""),
+               "last_err": err_last, "check": check,
+               # flat copies: the driver's parser drops nested objects
+               "check_idx_equal_bruteforce": None if check is None else check["idx_equal_bruteforce"],
+               "n_checked": None if check is None else check["n_checked"],
+               "collectives": ("library RCCL (icp_rccl_create): zero host callbacks" if lib_rccl is not None else
+                               ("host callback over torch.distributed" if comm is not None else "none (one rank)"))}
         out = {
             "metric": "closest-point queries/s over full ICP iterations (Match+FindTransform+apply+Distance), %s pts" % (
                 "1Mx1M" if n == (1 << 20) else "%dx%d" % (n, n)),
@@ -374,14 +497,45 @@ def main():
             "roofline": roof,
             "extra": extra,
         }
+        return out
+
+    # ---- N > 1: BASELINE configs C4 and C5 through the sharded entry points (extra.c4 / extra.c5).  The line above is
+    # complete without them: a watchdog prints it and ends the process if a leg overruns its deadline (a hung collective
+    # on a node nobody could rehearse on must not cost the headline measurement).
+    if distributed and not args.no_multi_legs and not args.brute:
+        import threading
+        state = {"printed": False}
+
+        def bail():
+            if rank == 0 and not state["printed"]:
+                state["printed"] = True
+                extra["multi_gpu_legs"] = "deadline of %.0f s exceeded: line printed without the unfinished legs" % args.legs_deadline
+                line = build_line()
+                line["cpu_baseline"] = None
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        guard = threading.Timer(args.legs_deadline + (0.0 if rank == 0 else 10.0), bail)
+        guard.daemon = True
+        guard.start()
+        for name, leg in (("c4", leg_c4), ("c5", leg_c5)):
+            try:
+                extra[name] = leg(args, ctx, comm, lib_rccl, world, rank, barrier)
+            except Exception as e:
+                extra[name] = {"error": repr(e)}
+        guard.cancel()
+
+    if rank == 0:
+        out = build_line()
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(src, tgt, min(args.cpu_sample, n), args.numpy_queries)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
-    if distributed or args.rehearse_comm:
+    if lib_rccl is not None:
+        lib_rccl.close()
+    if distributed or (args.rehearse_comm and lib_rccl is None):
         dist.destroy_process_group()
 
 

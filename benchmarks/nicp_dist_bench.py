@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--maxcg", type=int, default=300)
     ap.add_argument("--cgtol", type=float, default=1e-6)
     ap.add_argument("--share-gpu", action="store_true")
+    ap.add_argument("--rccl", action="store_true", help="library-side RCCL (icp_rccl_create): the collectives are issued by the library, no callbacks")
+    ap.add_argument("--force", action="store_true", help="ICP_COMM_FORCE: one rank runs the whole sharded code path, every collective issued")
+    ap.add_argument("--single", action="store_true", help="one rank through nicp_solve (the single-GPU entry point) for comparison")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -53,7 +56,19 @@ def main():
     nbr, wt = w.nbr.cpu().numpy(), w.wt.cpu().numpy()
     t_init = time.perf_counter() - t0
     t0 = time.perf_counter()
-    sh = nicp_dist.ShardedNICP(v, nbr, wt, edges, tgt, world=world, rank=rank, ctx=ctx)
+    lib_rccl = _lib.LibraryRccl(ctx, rank=rank, world=world) if args.rccl else None
+    sh = nicp_dist.ShardedNICP(v, nbr, wt, edges, tgt, world=world, rank=rank, ctx=ctx, rccl=lib_rccl, force=args.force)
+    if args.single:
+        class Single:                                   # same timing harness over nicp_solve
+            P = ctx.to_dev(nicp.initial_params(n, 3))
+            shard = sh.shard
+            comm = sh.comm
+            match = sh.match
+            def solve(self, nn, c, opts):
+                Pn, st = nicp.solve(self.P, w, v, edges, nn, c, compat=False, opts=opts, ctx=ctx)
+                self.P.copy_(Pn)
+                return st
+        sh = Single()
     t_part = time.perf_counter() - t0
     nn = sh.match()
     opts = dict(max_lm_iters=args.lm, max_cg_iters=args.maxcg, cg_tol=args.cgtol)
@@ -82,7 +97,9 @@ def main():
                           "n_ranks": world, "seconds": dt, "lm_iters": st["lm_iters"], "cg_iters": st["cg_iters"],
                           "cg_iters_per_s": st["cg_iters"] / dt, "us_per_cg_iter": dt / max(st["cg_iters"], 1) * 1e6,
                           "err0": st["err0"], "err": st["err"], "owned": sh.shard.n_owned, "halo": sh.shard.n_halo,
-                          "comm_calls": sh.comm.calls, "knn_weights_s": t_init, "partition_s": t_part}))
+                          "comm_calls": sh.comm.calls, "knn_weights_s": t_init, "partition_s": t_part,
+                          "path": "nicp_solve" if args.single else ("nicp_solve_dist, library RCCL" if args.rccl else "nicp_solve_dist, callbacks"),
+                          "graph_launches": st["graph_launches"], "forced": bool(args.force)}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

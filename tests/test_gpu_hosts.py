@@ -263,15 +263,42 @@ def test_bench_contract_line():
     assert d["value"] > 0 and abs(d["value"] - 65536 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma", "valu") and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the grid search is bound by instruction issue and the L1 address path, not by HBM: the label says so
+    assert r["bound"].startswith("latency") and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0 < r["frac_compulsory"] <= r["frac"] and r["compulsory_bytes"] == 24 * 65536 + 24 * 65536 + 4 * 65536
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert c["nproc"] >= 1 and c["cpu_model"] and c["numpy_reference"]["closest_queries_per_s"] > 0
     assert d["config"]["check"] == dict(d["config"]["check"], idx_equal_bruteforce=True, n_checked=65536)
+    assert d["config"]["check_idx_equal_bruteforce"] is True and d["config"]["n_checked"] == 65536      # flat, for the driver's parser
     assert r["bruteforce_kernel"]["bound"] == "valu" and r["bruteforce_kernel"]["frac"] > 0
     e = d["extra"]
     assert len(e["timed_calls_ms_per_step"]) == 3 and e["repeats"]["min_ms_per_step"] <= d["ms_per_step"] <= e["repeats"]["max_ms_per_step"]
     assert e["setup_ms"] is not None
+
+
+def test_bench_multi_gpu_legs_rehearsal():
+    """bench.py --gpus 2 as the driver launches it, rehearsed on the one GPU of the box (--share-gpu: both ranks on GPU 0,
+    collectives over gloo through the callbacks): the line carries extra.c4 and extra.c5 (BASELINE configs 4 and 5 through
+    the sharded entry points, here at reduced sizes), each with its own check / counters."""
+    import json
+    import sys
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "131072",
+           "--repeats", "1", "--share-gpu", "--c4-n", "262144", "--c5-nx", "60"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["check_idx_equal_bruteforce"] is True and d["config"]["n_checked"] == 131072
+    c4, c5 = d["extra"]["c4"], d["extra"]["c5"]
+    assert "error" not in c4 and "error" not in c5, (c4, c5)
+    assert c4["check_idx_equal_bruteforce"] is True and c4["rows_per_rank"] == 131072 and c4["queries_per_s"] > 0
+    assert c4["host_callbacks"] > 0                     # gloo rehearsal: the callback path (library RCCL would read 0)
+    assert c5["cg_iters"] > 0 and c5["cg_iters_per_s"] > 0 and c5["err"] < c5["err0"] and 0 < c5["halo_fraction"] < 1
+    assert c5["owned_vertices"] == 1800 and c5["collectives_per_cg_iteration"] == 3
 
 
 @pytest.mark.gpu
