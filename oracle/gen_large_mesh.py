@@ -14,7 +14,7 @@ make_grid_mesh(100, 100, seed=7)) and writes what the GPU tests compare with:
 
 One sparse factorisation takes 7 s (2 500 vertices) / 50 s (10 000) on one core, which is why these are fixtures and
 not computed inside the GPU tests; tests/test_oracle_sparse_cpu.py re-derives part of the 2 500-vertex file on every
-CPU run so that the fixtures cannot drift from the oracle.  Usage:  python oracle/gen_large_mesh.py [2500|10000|solve]
+CPU run so that the fixtures cannot drift from the oracle.  Usage:  python oracle/gen_large_mesh.py [2500|10000 [case]|solve|merge 10000]
 """
 import hashlib
 import os
@@ -69,7 +69,9 @@ def checkpoint(out, key, P, Ps, d):
     out[key + "_delta_proj"] = projections(len(P)) @ delta
 
 
-def lm_cases(nx):
+def lm_cases(nx, only=None):
+    """only = "<mode>_<start>": that case alone into a part file (the four cases of the 10 000-vertex mesh are run as four
+    processes, 3 - 17 minutes each); `merge` joins the parts."""
     d = inputs(nx)
     n = len(d["v"])
     out = dict(nx=nx, n=n, stride=STRIDE, inputs_sha1=digest(d["v"], d["edges"], d["nn"], d["nbr"]),
@@ -77,6 +79,8 @@ def lm_cases(nx):
     for compat in (True, False):
         for start in ("P0", "Ppert"):
             key = "%s_%s" % ("compat" if compat else "corrected", start)
+            if only and key != only:
+                continue
             t0 = time.time()
             tr = []
             P, info = ors.lm_sparse(d[start], d["nbr"], d["wt"], d["v"], d["edges"], d["nn"], C, compat, steps=3,
@@ -98,6 +102,19 @@ def lm_cases(nx):
                         out["%s_s%d_nfev" % (key, k)] = 1 + int(np.nonzero(acc)[0][k - 1]) + 1
             print(key, "trials", len(tr), "accepted", int(acc.sum()), "lam", out[key + "_lam"], "f2t", out[key + "_f2t"],
                   "max solve residual %.1e" % out[key + "_solve_residual"].max(), "%.0f s" % (time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(GOLDEN, "nicp_large_%d%s.npz" % (n, "_part_" + only if only else "")), **out)
+
+
+def merge(n):
+    out = {}
+    for key in ("compat_P0", "compat_Ppert", "corrected_P0", "corrected_Ppert"):
+        path = os.path.join(GOLDEN, "nicp_large_%d_part_%s.npz" % (n, key))
+        part = np.load(path)
+        for k in part.files:
+            if k in out and not k.startswith(key):
+                assert np.array_equal(out[k], part[k]), k
+            out[k] = part[k]
+        os.remove(path)
     np.savez_compressed(os.path.join(GOLDEN, "nicp_large_%d.npz" % n), **out)
 
 
@@ -144,5 +161,7 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "2500"
     if what == "solve":
         whole_solve()
+    elif what == "merge":
+        merge(int(sys.argv[2]))
     else:
-        lm_cases({"2500": 50, "10000": 100}[what])
+        lm_cases({"2500": 50, "10000": 100}[what], sys.argv[2] if len(sys.argv) > 2 else None)
