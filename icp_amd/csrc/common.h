@@ -133,6 +133,7 @@ int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *t
                      unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done,
                      const GridBuild *grid = nullptr, const int32_t *hint_from = nullptr, const FusedApply *fa = nullptr);
 bool grid_worthwhile(int64_t n, int64_t m, unsigned flags);
+bool grid_fusable();  // false under the single-pass switches of the grid search: rigid loops then take the unfused form
 // exact k nearest (k = 6 or 8) by the key fl(sqrt(d2)), ties to the lower index, through a built grid
 int grid_knn(icp_ctx *ctx, const GridBuild &gb, const double *q, int64_t nq, int k, int32_t *idx_out, double *dist_out);
 

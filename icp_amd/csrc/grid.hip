@@ -1025,7 +1025,8 @@ constexpr int kKnnStack = 64;   // cells on a lane's stack
 template <int DIM, int K>
 __global__ __launch_bounds__(GB) void grid_knn_kernel(const double *__restrict__ qpts, int64_t nq,
                                                      const double4 *__restrict__ recs, const uint32_t *__restrict__ start,
-                                                     GridParams gp, int32_t *__restrict__ idx_out, double *__restrict__ dist_out) {
+                                                     GridParams gp, int32_t *__restrict__ idx_out, double *__restrict__ dist_out,
+                                                     int defer_from, int32_t *__restrict__ dlist, uint32_t *__restrict__ ndef) {
     const int64_t t = (int64_t)blockIdx.x * GB + threadIdx.x;
     if (t >= nq) return;
     double s[DIM];
@@ -1050,6 +1051,13 @@ __global__ __launch_bounds__(GB) void grid_knn_kernel(const double *__restrict__
         cell_of<DIM>(s, gp, c0);
         constexpr int NBR = DIM == 3 ? 27 : 9;
         for (int l = 0; l <= gp.bits; ++l) {
+            if (l >= defer_from) {
+                // A query whose k nearest are not within the 3^DIM boxes of the first levels (a stray vertex far from the
+                // mesh, a hole) would climb on alone while its wave waits: it goes to the wave-per-query pass instead
+                // (grid_knn_defer_kernel), which starts again from the root.
+                dlist[atomicAdd(ndef, 1u)] = (int32_t)t;
+                return;
+            }
             reset();
             double gate = __builtin_inf();
             const double hl = gp.h * (double)(1 << l);
@@ -1209,15 +1217,247 @@ __global__ __launch_bounds__(GB) void grid_knn_kernel(const double *__restrict__
     }
 }
 
+
+// Second pass of the grid KNN: ONE WAVE PER QUERY for the queries the per-lane pass handed over.  A descent from the
+// root cell over a stack of cells in LDS.  Each round takes up to 64 cells off the top, ONE PER LANE (a single cell while
+// the list of k is not full yet: plain depth-first to the nearest leaf, so the k-th key exists before anything wide
+// happens): bound test -- a cell is dropped when fl(sqrt(bound)) > k-th key; a tie must be visited, it may carry a
+// lower index -- and range lookup run in parallel, so a round costs the two dependent memory latencies once, not once
+// per cell (one wave walking cell by cell took 2.5 ms for a vertex 50 sigma from a 200 000-point cloud: the ball of
+// its k-th key cuts through hundreds of sparsely filled cells).  A cell above the finest level with more than
+// kKnnWaveScan records is replaced by its 2^DIM children (farthest first within the cell, so the nearest ends up on
+// top), the others' ranges are concatenated and scanned by all 64 lanes, 64 records per step, each record re-tested
+// against its cell's bound as the k-th key tightens.  Children partition their parent, so no record is met twice.
+// The k best (key, index) pairs are held identically by every lane; after a step the lanes whose record can enter are
+// taken in (key, index) order by wave-wide minima.  Same keys, same tie rule, same bounds as the per-lane pass: the
+// result is the same list bit for bit (tests/test_gpu_nicp.py::test_knn_far_strays_and_duplicates).
+constexpr int kKnnWaveScan = 128;
+constexpr int kKnnWaveStack = 1024;
+
+template <int DIM, int K>
+__global__ __launch_bounds__(64) void grid_knn_defer_kernel(const double *__restrict__ qpts, const double4 *__restrict__ recs,
+                                                           const uint32_t *__restrict__ start, GridParams gp,
+                                                           const int32_t *__restrict__ dlist, const uint32_t *__restrict__ ndef,
+                                                           int32_t *__restrict__ idx_out, double *__restrict__ dist_out) {
+    __shared__ uint32_t stk[kKnnWaveStack];
+    __shared__ uint32_t pre[65], rq0[64];
+    __shared__ double rbound[64];
+    constexpr int NCH = 1 << DIM;
+    const int lane = threadIdx.x;
+    const uint32_t nd = *ndef;
+    for (uint32_t qi = blockIdx.x; qi < nd; qi += gridDim.x) {
+        const int64_t t = dlist[qi];
+        double s[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) s[a] = qpts[t * DIM + a];
+        double key[K];
+        int32_t id[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            key[k] = __builtin_inf();
+            id[k] = 0x7fffffff;
+        }
+        double gate = __builtin_inf();
+        auto cell_bound = [&](const int *y, int lv) {   // the per-lane pass's bound, operation for operation
+            const double hv = gp.h * (double)(1 << lv);
+            const int nv = 1 << (gp.bits - lv);
+            const double slv = hv * 0x1p-20;
+            double bound = 0.0;
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) {
+                const double sl = slv + (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
+                const double lo = gp.mn[a] + (double)y[a] * hv, hi = gp.mn[a] + (double)(y[a] + 1) * hv;
+                double g = lo - s[a] - sl;
+                double gh = s[a] - hi - sl;
+                open_sides(gp, a, y[a], nv, g, gh);
+                g = gh > g ? gh : g;
+                g = g > 0.0 ? g : 0.0;
+                bound = bound + g * g;
+            }
+            return bound;
+        };
+        __syncthreads();   // (block = one wave) the previous query's stack is dead
+        if (lane == 0) {
+            int root[DIM];
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) root[a] = 0;
+            stk[0] = pack_cell<DIM>(root, gp.bits);
+        }
+        int sp = 1;   // uniform
+        __syncthreads();
+        while (sp > 0) {
+            const int take = key[K - 1] == __builtin_inf() ? 1 : (sp < 64 ? sp : 64);
+            const int base = sp - take;
+            // lane i < take: cell base + take - 1 - i (lane 0 holds the top of the stack = the nearest)
+            int y[DIM], lv = 0;
+            bool alive = lane < take;
+            double bnd = 0.0;
+            uint32_t q0 = 0, cnt = 0;
+            if (alive) {
+                unpack_cell<DIM>(stk[base + take - 1 - lane], y, lv);
+                bnd = __dsqrt_rn(cell_bound(y, lv));
+                alive = !(bnd > key[K - 1]);
+            }
+            if (alive) {
+                const uint32_t cc = morton<DIM>(y);
+                q0 = start[(uint64_t)cc << (DIM * lv)];
+                cnt = start[((uint64_t)cc + 1) << (DIM * lv)] - q0;
+                alive = cnt > 0;
+            }
+            bool split = alive && lv > 0 && cnt > (uint32_t)kKnnWaveScan;
+            const unsigned long long sm = __ballot(split);
+            const int srank = __popcll(sm & ((1ull << lane) - 1ull));
+            if (split && base + (srank + 1) * NCH > kKnnWaveStack) split = false;   // no room for its children: scanned whole
+            const int nsplit = __popcll(__ballot(split));
+            __syncthreads();   // every lane has read its entry of the stack
+            if (split) {
+                // children farthest first: the last split lane's nearest child ends on top
+                double cb[NCH];
+                uint32_t cn[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    int z[DIM];
+#pragma unroll
+                    for (int a = 0; a < DIM; ++a) z[a] = 2 * y[a] + ((c >> a) & 1);
+                    cb[c] = cell_bound(z, lv - 1);
+                    cn[c] = pack_cell<DIM>(z, lv - 1);
+                }
+                // lane 0 is the nearest cell of the batch: its children must come last (top), so split lane r writes block nsplit-1-r
+                uint32_t *dst = stk + base + (nsplit - 1 - srank) * NCH;
+                for (int i = 0; i < NCH; ++i) {
+                    int mx = -1;
+                    for (int c = 0; c < NCH; ++c)
+                        if (cn[c] != 0xffffffffu && (mx < 0 || cb[c] > cb[mx])) mx = c;
+                    dst[i] = cn[mx];
+                    cn[mx] = 0xffffffffu;
+                }
+            }
+            sp = base + nsplit * NCH;
+            // the other live cells: concatenate their ranges and scan them with all lanes
+            const bool scan = alive && !split;
+            uint32_t incl = scan ? cnt : 0u;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+            pre[lane] = incl - (scan ? cnt : 0u);
+            rq0[lane] = q0;
+            rbound[lane] = bnd;
+            if (lane == 63) pre[64] = total;
+            __syncthreads();
+            for (uint32_t off = 0; off < total; off += 64) {
+                const uint32_t i = off + (uint32_t)lane;
+                bool cand = false;
+                double r = __builtin_inf();
+                int32_t jj = 0x7fffffff;
+                if (i < total) {
+                    int lo = 0, hi = 63;
+#pragma unroll
+                    for (int it = 0; it < 6; ++it) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (pre[mid] <= i) lo = mid;
+                        else hi = mid - 1;
+                    }
+                    if (!(rbound[lo] > key[K - 1])) {   // the cell may have fallen behind the k-th key since it was listed
+                        const double4 rc = recs[rq0[lo] + (i - pre[lo])];
+                        double d2 = 0.0;
+                        const double dx = rc.x - s[0], dy = rc.y - s[1];
+                        d2 += dx * dx;
+                        d2 += dy * dy;
+                        if (DIM == 3) {
+                            const double dz = rc.z - s[DIM - 1];
+                            d2 += dz * dz;
+                        }
+                        if (d2 <= gate) {
+                            r = __dsqrt_rn(d2);
+                            jj = (int32_t)__double_as_longlong(rc.w);
+                            cand = r < key[K - 1] || (r == key[K - 1] && jj < id[K - 1]);
+                        }
+                    }
+                }
+                while (__ballot(cand)) {   // uniform
+                    double mr = cand ? r : __builtin_inf();
+                    int32_t mi = cand ? jj : 0x7fffffff;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const double orr = shfl_xor_f64(mr, o);
+                        const int32_t oi = __shfl_xor(mi, o, 64);
+                        if (orr < mr || (orr == mr && oi < mi)) {
+                            mr = orr;
+                            mi = oi;
+                        }
+                    }
+                    // (mr, mi) is the best pending candidate, and it beats the k-th entry: insert it (every lane alike)
+                    double ck = mr;
+                    int32_t ci = mi;
+                    bool shifting = false;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const bool sw = shifting || ck < key[k] || (ck == key[k] && ci < id[k]);
+                        shifting = sw;
+                        const double tk = sw ? key[k] : ck;
+                        const int32_t ti = sw ? id[k] : ci;
+                        key[k] = sw ? ck : key[k];
+                        id[k] = sw ? ci : id[k];
+                        ck = tk;
+                        ci = ti;
+                    }
+                    if (cand && jj == mi) cand = false;   // indices are unique: that lane's record is in
+                    cand = cand && (r < key[K - 1] || (r == key[K - 1] && jj < id[K - 1]));
+                }
+                const double kr = key[K - 1];
+                gate = (kr > 1e-150 && kr < 1e150) ? kr * kr * (1.0 + 0x1p-50) : __builtin_inf();
+            }
+            __syncthreads();   // pre / rq0 / rbound are rewritten by the next round
+        }
+        if (lane < K) {
+            // every lane holds the list; lane k writes entry k
+            double kk = key[0];
+            int32_t ii = id[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k)
+                if (lane == k) {
+                    kk = key[k];
+                    ii = id[k];
+                }
+            idx_out[t * K + lane] = ii == 0x7fffffff ? -1 : ii;
+            dist_out[t * K + lane] = kk;
+        }
+    }
+}
+
 int grid_knn(icp_ctx *ctx, const GridBuild &gb, const double *q, int64_t nq, int k, int32_t *idx_out, double *dist_out) {
     const unsigned nb = (unsigned)((nq + GB - 1) / GB);
     hipStream_t st = ctx->stream;
     const double4 *recs = (const double4 *)gb.recs;
     const uint32_t *start = (const uint32_t *)gb.start;
-    if (gb.gp.dim == 3 && k == 6) hipLaunchKernelGGL((grid_knn_kernel<3, 6>), dim3(nb), dim3(GB), 0, st, q, nq, recs, start, gb.gp, idx_out, dist_out);
-    else if (gb.gp.dim == 3) hipLaunchKernelGGL((grid_knn_kernel<3, 8>), dim3(nb), dim3(GB), 0, st, q, nq, recs, start, gb.gp, idx_out, dist_out);
-    else if (k == 6) hipLaunchKernelGGL((grid_knn_kernel<2, 6>), dim3(nb), dim3(GB), 0, st, q, nq, recs, start, gb.gp, idx_out, dist_out);
-    else hipLaunchKernelGGL((grid_knn_kernel<2, 8>), dim3(nb), dim3(GB), 0, st, q, nq, recs, start, gb.gp, idx_out, dist_out);
+    // queries still open after the levels below `defer_from` go to the wave-per-query pass (ICP_KNN_DEFER: that level;
+    // a value above every level keeps the per-lane pass alone, round 2's behaviour)
+    static const int defer_env = getenv("ICP_KNN_DEFER") ? atoi(getenv("ICP_KNN_DEFER")) : 2;
+    const int defer_from = defer_env > 0 ? defer_env : 1000;
+    // the list lives in the scratch of the closest-point search's deferred pass (never in use at the same time); its
+    // counter is word 2 of the header, the search's own two counters are left alone
+    const size_t cap0 = ctx->defer.cap;
+    if (int rc = ensure(ctx, ctx->defer, (size_t)nq * sizeof(int32_t) + 256)) return rc;
+    if (ctx->defer.cap != cap0) ctx->defer_cleared = nullptr;
+    uint32_t *ndef = (uint32_t *)ctx->defer.ptr + 2;
+    int32_t *dlist = (int32_t *)((char *)ctx->defer.ptr + 256);
+    ICP_HIP_CHECK(hipMemsetAsync(ndef, 0, sizeof(uint32_t), st));
+    const unsigned nb2 = (unsigned)(nq < 4096 ? nq : 4096);
+#define ICP_KNN(D, KK) \
+    do { \
+        hipLaunchKernelGGL((grid_knn_kernel<D, KK>), dim3(nb), dim3(GB), 0, st, q, nq, recs, start, gb.gp, idx_out, dist_out, defer_from, dlist, ndef); \
+        if (defer_from < 1000) \
+            hipLaunchKernelGGL((grid_knn_defer_kernel<D, KK>), dim3(nb2), dim3(64), 0, st, q, recs, start, gb.gp, (const int32_t *)dlist, \
+                               (const uint32_t *)ndef, idx_out, dist_out); \
+    } while (0)
+    if (gb.gp.dim == 3 && k == 6) ICP_KNN(3, 6);
+    else if (gb.gp.dim == 3) ICP_KNN(3, 8);
+    else if (k == 6) ICP_KNN(2, 6);
+    else ICP_KNN(2, 8);
+#undef ICP_KNN
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
 }
@@ -1422,13 +1662,20 @@ int grid_build_finish(icp_ctx *ctx, const GridPending &pend, GridBuild &gb) {
 long long *g_grid_dbg = nullptr;    // per-lane instrumentation (ICP_GRID_DEBUG in icp_bench_grid_query)
 hipEvent_t *g_grid_events = nullptr;  // [3]: before the per-lane pass, between the passes, after the deferred pass
 
+// levels the per-lane pass handles itself (ICP_GRID_CAP=0: all of them, single pass)
+static int grid_cap() {
+    static const int cap_env = getenv("ICP_GRID_CAP") ? atoi(getenv("ICP_GRID_CAP")) : 1;
+    return g_grid_dbg ? 1000 : (cap_env > 0 ? cap_env : 1000);
+}
+// The fused rigid loop needs the two-pass search: under the single-pass switches (ICP_GRID_CAP=0, ICP_GRID_DEBUG) the
+// callers keep the moved source as an array instead (the ICP_NO_FUSE form), they do not fail.
+bool grid_fusable() { return grid_cap() < 1000; }
+
 int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
                const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done, const int32_t *hint, bool pos_mode,
                const FusedApply *fa) {
     hipStream_t st = ctx->stream;
-    // levels the per-lane pass handles itself (ICP_GRID_CAP=0: all of them, single pass)
-    static const int cap_env = getenv("ICP_GRID_CAP") ? atoi(getenv("ICP_GRID_CAP")) : 1;
-    const int cap = g_grid_dbg ? 1000 : (cap_env > 0 ? cap_env : 1000);
+    const int cap = grid_cap();
     const size_t defer_cap = ctx->defer.cap;
     if (int rc = ensure(ctx, ctx->defer, (size_t)n * sizeof(Deferred) + 256)) return rc;
     if (ctx->defer.cap != defer_cap) ctx->defer_cleared = nullptr;   // reallocated (possibly at the same address)

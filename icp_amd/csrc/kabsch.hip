@@ -901,7 +901,7 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
     // Morton-sorted copy of the target (queries are in Morton order too, so neighbouring lanes read neighbouring
     // records) and last iteration's position is the next search's hint directly.
     const bool pos = grid.usable && !(flags & ICP_FORCE_BRUTE);
-    const bool fused = pos && !(flags & (ICP_COMPARE_SQRT | ICP_NO_FUSE));
+    const bool fused = pos && !(flags & (ICP_COMPARE_SQRT | ICP_NO_FUSE)) && grid_fusable();
     double *ss = nullptr;
     if (!fused) {
         if (int rc = ensure(ctx, ctx->work_c, (size_t)n * dim * sizeof(double))) return rc;

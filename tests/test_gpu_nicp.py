@@ -273,6 +273,38 @@ def test_knn_grid_equals_full_scan(mods, kind, monkeypatch):
     assert np.array_equal(si.cpu().numpy(), oi) and np.array_equal(sd.cpu().numpy(), od)
 
 
+@pytest.mark.parametrize("kind", ["strays", "strays_dups", "two_islands", "plane2d_strays"])
+def test_knn_far_strays_and_duplicates(mods, kind, monkeypatch):
+    """vertices far from the mesh (and exact duplicates of them, and of mesh vertices) leave the
+    per-lane pass of the grid KNN after two levels and are finished by the wave-per-query pass (grid_knn_defer_kernel):
+    indices AND keys must equal the full scan's bit for bit, k = 6 and 8, as queries against the set itself (the
+    Initialise case) and as foreign queries."""
+    nic = mods["nicp"]
+    rng = np.random.default_rng(23)
+    if kind == "plane2d_strays":
+        v = np.concatenate([rng.uniform(-1, 1, (30000, 2)), rng.uniform(-1, 1, (12, 2)) * 40.0, np.full((7, 2), 55.0)])
+    else:
+        v = orc.make_grid_mesh(200, 150, seed=3)[0]
+        strays = rng.standard_normal((10, 3)) * 8.0 + 12.0
+        if kind == "strays":
+            v = np.concatenate([v, strays])
+        elif kind == "strays_dups":
+            v = np.concatenate([v, strays, strays[:4], strays[:4], v[:500], v[1000:1200]])   # exact ties far out and inside
+        else:
+            v = np.concatenate([v, v[:4000] * 0.05 + np.array([30.0, -20.0, 10.0])])             # a second, tiny island far away
+    q = np.concatenate([v[::11], v[-40:], rng.uniform(v.min(), v.max(), (300, v.shape[1])), v[:20] * 3.0 + 100.0])
+    out = {}
+    for mode, env in (("grid", "1"), ("scan", "1000000000")):
+        monkeypatch.setenv("ICP_KNN_GRID_MIN", env)
+        out[mode] = [nic.knn(v, v, 6), nic.knn(v, q, 6), nic.knn(v, q, 8)]
+    for (gi, gd), (bi, bd) in zip(out["grid"], out["scan"]):
+        assert np.array_equal(gi.cpu().numpy(), bi.cpu().numpy()), kind
+        assert np.array_equal(gd.cpu().numpy(), bd.cpu().numpy()), kind
+    if kind == "strays":
+        oi, od = c_oracle.knn_rows(v, 6)
+        assert np.array_equal(out["grid"][0][0].cpu().numpy(), oi) and np.array_equal(out["grid"][0][1].cpu().numpy(), od)
+
+
 def test_cg_graph_replay_is_bit_identical(mods, monkeypatch):
     """The hipGraph replay of the CG iterations (single GPU) launches the same kernels with the same
     arguments: parameters, energies and iteration counts must not change by a bit."""

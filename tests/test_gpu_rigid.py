@@ -472,3 +472,39 @@ def test_stream_handover_after_the_old_stream_is_destroyed(mode):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", _STREAM_HANDOVER % root, mode], capture_output=True, text=True, timeout=110)
     assert out.returncode == 0 and "handover ok" in out.stdout, out.stdout + out.stderr
+
+
+_SINGLE_PASS = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import icp_oracle as orc
+from icp_amd import rigid
+src, tgt = orc.make_rigid_cloud(150000, seed=21)
+r = rigid.rigid_icp(src, tgt, -np.inf, 4, want_idx=True)
+np.save(sys.argv[1], np.concatenate([r["T"].cpu().numpy().ravel(), r["err_hist"].cpu().numpy()[:4], r["idx"].cpu().numpy().astype(np.float64)]))
+print("single pass ok")
+"""
+
+
+def test_rigid_run_under_the_single_pass_switch(tmp_path):
+    """ICP_GRID_CAP=0 (the documented single-pass search) used to make icp_rigid_run fail at iteration 2 --
+    the fused loop was chosen from the flags alone and the search then refused it.  The loop now takes the unfused form
+    there: same transform and correspondences bit for bit, errors equal up to summation order."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for cap in (None, "0"):
+        env = dict(os.environ)
+        env.pop("ICP_GRID_CAP", None)
+        if cap is not None:
+            env["ICP_GRID_CAP"] = cap
+        f = str(tmp_path / ("run_%s.npy" % cap))
+        out = subprocess.run([sys.executable, "-c", _SINGLE_PASS % (root, os.path.join(root, "oracle")), f], capture_output=True,
+                             text=True, timeout=110, env=env)
+        assert out.returncode == 0 and "single pass ok" in out.stdout, out.stdout + out.stderr
+        outs.append(np.load(f))
+    a, b = outs
+    assert np.array_equal(a[:16], b[:16]) and np.array_equal(a[20:], b[20:])
+    np.testing.assert_allclose(a[16:20], b[16:20], rtol=1e-12)
