@@ -78,7 +78,7 @@ _SIGNATURES = {
 class SolveOpts(ctypes.Structure):
     """nicp_solve_opts of include/icp_hip.h"""
     _fields_ = [("ftol", c_dbl), ("xtol", c_dbl), ("gtol", c_dbl), ("lambda0", c_dbl), ("cg_tol", c_dbl),
-                ("max_lm_iters", c_int), ("max_cg_iters", c_int)]
+                ("max_lm_iters", c_int), ("max_cg_iters", c_int), ("accel", c_int)]
 
 
 class SolveStats(ctypes.Structure):

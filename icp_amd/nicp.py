@@ -257,7 +257,7 @@ def solve(P, w, source, edges, nn, c, compat=True, opts=None, ctx=None):
     nnd = ctx.to_dev(nn)
     o = None
     if opts:
-        o = _lib.SolveOpts(1.49012e-8, 1.49012e-8, 0.0, 1e-3, 0.0, 0, 0)
+        o = _lib.SolveOpts(1.49012e-8, 1.49012e-8, 0.0, 1e-3, 0.0, 0, 0, 0)
         for k, val in opts.items():
             setattr(o, k, val)
     st = _lib.SolveStats()

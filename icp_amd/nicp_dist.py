@@ -326,7 +326,7 @@ class ShardedNICP:
     def solve(self, nn, c, opts=None):
         o = None
         if opts:
-            o = _lib.SolveOpts(1.49012e-8, 1.49012e-8, 0.0, 1e-3, 0.0, 0, 0)
+            o = _lib.SolveOpts(1.49012e-8, 1.49012e-8, 0.0, 1e-3, 0.0, 0, 0, 0)
             for k, val in opts.items():
                 setattr(o, k, val)
         st = _lib.SolveStats()

@@ -293,6 +293,12 @@ typedef struct nicp_solve_opts {
                                 100 * (n + 1) residual evaluations (MINPACK's maxfev default, nicp_3d.py:351), which
                                 always applies; stats.info = 5 says that a limit ended the solve */
     int max_cg_iters;        /* per linear solve (0 = automatic) */
+    int accel;               /* accelerated LM iteration: every step gets the second-order (geodesic acceleration) correction
+                                -1/2 (J^T J + lambda D^2)^-1 J^T r''(d, d), r'' by central differences of the residual, and an
+                                automatic cg_tol starts at 0.3 and returns to its tight value before the stopping tests are
+                                accepted.  0 (default): automatic = on in the self-consistent mode, off under
+                                NICP_REFERENCE_COMPAT; 1: on; -1: off (the plain iteration, step for step
+                                what the oracle's lm_dense / lm_sparse restate).  Same minimiser either way. */
 } nicp_solve_opts;
 typedef struct nicp_solve_stats {
     double err;  /* sum of squared residuals at the returned P (nicp_3d.py:353) */

@@ -76,15 +76,17 @@ def lm_cases(nx, only=None):
     n = len(d["v"])
     out = dict(nx=nx, n=n, stride=STRIDE, inputs_sha1=digest(d["v"], d["edges"], d["nn"], d["nbr"]),
                meta_numpy=np.__version__)
-    for compat in (True, False):
+    # modes: the reference's (compat), the self-consistent one with the plain LM iteration (corrected) and with the
+    # accelerated iteration that is its default (accel: second-order correction of every step, nicp_solve_opts::accel)
+    for mode, compat, accel in (("compat", True, False), ("corrected", False, False), ("accel", False, True)):
         for start in ("P0", "Ppert"):
-            key = "%s_%s" % ("compat" if compat else "corrected", start)
+            key = "%s_%s" % (mode, start)
             if only and key != only:
                 continue
             t0 = time.time()
             tr = []
             P, info = ors.lm_sparse(d[start], d["nbr"], d["wt"], d["v"], d["edges"], d["nn"], C, compat, steps=3,
-                                    ftol=0.0, xtol=0.0, trace=tr)
+                                    ftol=0.0, xtol=0.0, trace=tr, accel=accel)
             acc = np.array([np.isfinite(t["f2t"]) and t["ratio"] > 1e-4 for t in tr])
             out[key + "_lam"] = np.array([t["lam"] for t in tr])
             out[key + "_f2t"] = np.array([t["f2t"] for t in tr])
@@ -99,19 +101,26 @@ def lm_cases(nx, only=None):
                     if k in (1, 3):
                         checkpoint(out, "%s_s%d" % (key, k), t["x"] + t["delta"], d[start], d)
                         out["%s_s%d_err" % (key, k)] = t["f2t"]
-                        out["%s_s%d_nfev" % (key, k)] = 1 + int(np.nonzero(acc)[0][k - 1]) + 1
+                        out["%s_s%d_nfev" % (key, k)] = 1 + (int(np.nonzero(acc)[0][k - 1]) + 1) * (3 if accel else 1)
             print(key, "trials", len(tr), "accepted", int(acc.sum()), "lam", out[key + "_lam"], "f2t", out[key + "_f2t"],
                   "max solve residual %.1e" % out[key + "_solve_residual"].max(), "%.0f s" % (time.time() - t0), flush=True)
     np.savez_compressed(os.path.join(GOLDEN, "nicp_large_%d%s.npz" % (n, "_part_" + only if only else "")), **out)
 
 
 def merge(n):
+    """join the part files (and what nicp_large_<n>.npz already holds) into nicp_large_<n>.npz"""
     out = {}
-    for key in ("compat_P0", "compat_Ppert", "corrected_P0", "corrected_Ppert"):
+    whole = os.path.join(GOLDEN, "nicp_large_%d.npz" % n)
+    if os.path.exists(whole):
+        old = np.load(whole)
+        out.update({k: old[k] for k in old.files})
+    for key in ("compat_P0", "compat_Ppert", "corrected_P0", "corrected_Ppert", "accel_P0", "accel_Ppert"):
         path = os.path.join(GOLDEN, "nicp_large_%d_part_%s.npz" % (n, key))
+        if not os.path.exists(path):
+            continue
         part = np.load(path)
         for k in part.files:
-            if k in out and not k.startswith(key):
+            if k in out and not k.startswith(key.split("_")[0]):
                 assert np.array_equal(out[k], part[k]), k
             out[k] = part[k]
         os.remove(path)

@@ -558,7 +558,7 @@ def nicp(P, nbr, wt, source, edges, target, tol, run, c=(C_FIT, C_RIGID, C_SMOOT
 
 
 def lm_dense(P0, nbr, wt, source, edges, nn, c=(C_FIT, C_RIGID, C_SMOOTH), compat=True, steps=1,
-             lambda0=1e-3, ftol=1.49012e-8, xtol=1.49012e-8, trace=None):
+             lambda0=1e-3, ftol=1.49012e-8, xtol=1.49012e-8, trace=None, accel=False):
     """Dense twin of the PRODUCT's Levenberg-Marquardt loop (icp_amd/csrc/nicp.hip, solve_impl), on this
     file's min_func / d_min_func -- NOT a restatement of MINPACK.  Test infrastructure: what the reference
     determines in compat mode is the pair (MinFunc, D_MinFunc), pinned to it at 1e-12 by the golden
@@ -569,7 +569,10 @@ def lm_dense(P0, nbr, wt, source, edges, nn, c=(C_FIT, C_RIGID, C_SMOOTH), compa
 
     Runs `steps` accepted steps (or stops on lmder's ftol / xtol tests) and returns
     (P, info dict(err0, err, nfev, lm_iters, info, lams)).  Acceptance: gain ratio > 1e-4 (lmder.f);
-    damping: Nielsen's update on acceptance, lam *= nu, nu *= 2 on rejection."""
+    damping: Nielsen's update on acceptance, lam *= nu, nu *= 2 on rejection.
+    accel=True: the product's accelerated iteration (nicp_solve_opts::accel): every step gets the second-order
+    correction d2 = -1/2 (J^T J + lam D^2)^-1 J^T (r(x+d1) - 2 r(x) + r(x-d1)), kept when |D d2| <= 0.75 |D d1|; the
+    gain ratio uses the first-order step's model."""
     x = np.array(P0, dtype=np.float64)
     f = lambda p: min_func(p, nbr, wt, source, edges, nn, c, compat)
     Jf = lambda p: d_min_func(p, nbr, wt, source, edges, nn, c, compat)
@@ -588,11 +591,18 @@ def lm_dense(P0, nbr, wt, source, edges, nn, c=(C_FIT, C_RIGID, C_SMOOTH), compa
         accepted = False
         while not accepted and not out["info"]:
             delta = np.linalg.solve(H + lam * np.diag(d2), -grad)
+            dmodel = delta
+            if accel:
+                fvv = f(x + delta) - 2.0 * r + f(x - delta)
+                out["nfev"] += 2
+                delta2 = np.linalg.solve(H + lam * np.diag(d2), -0.5 * (J.T @ fvv))
+                if float((delta2 * delta2 * d2).sum()) <= 0.5625 * float((delta * delta * d2).sum()):
+                    delta = delta + delta2
             xt = x + delta
             rt = f(xt)
             f2t = float(rt @ rt)
             out["nfev"] += 1
-            dn2, dg, xn2 = float((delta * delta * d2).sum()), float(delta @ grad), float((x * x * d2).sum())
+            dn2, dg, xn2 = float((dmodel * dmodel * d2).sum()), float(dmodel @ grad), float((x * x * d2).sum())
             pred, actred = lam * dn2 - dg, f2 - f2t
             ratio = actred / pred if pred > 0 else (1.0 if actred > 0 else -1.0)
             if trace is not None:

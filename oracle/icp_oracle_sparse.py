@@ -220,11 +220,14 @@ class NormalSolver:
 
     def solve(self, lam, d2, rhs):
         nv, perm = self.nv, self.perm
-        M = (self.Hvv + sp.diags(lam * d2[:nv])).tocsc()[perm][:, perm]
-        lu = spla.splu(M.tocsc(), permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
-        ng = self.Jg.shape[1]
-        Y = np.empty((nv, ng))
-        Y[perm] = lu.solve(self.Hvg[perm])
+        key = (float(lam), hash(d2.tobytes()))
+        if getattr(self, "_key", None) != key:      # (a second right-hand side under the same damping reuses the factors)
+            M = (self.Hvv + sp.diags(lam * d2[:nv])).tocsc()[perm][:, perm]
+            lu = spla.splu(M.tocsc(), permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+            Y = np.empty((nv, self.Jg.shape[1]))
+            Y[perm] = lu.solve(self.Hvg[perm])
+            self._key, self._lu, self._Y = key, lu, Y
+        lu, Y = self._lu, self._Y
         S = self.Hgg + np.diag(lam * d2[nv:]) - self.Hvg.T @ Y
 
         def once(b):
@@ -241,7 +244,7 @@ class NormalSolver:
 
 
 def lm_sparse(P0, nbr, wt, source, edges, nn, c=(orc.C_FIT, orc.C_RIGID, orc.C_SMOOTH), compat=True, steps=1,
-              lambda0=1e-3, ftol=1.49012e-8, xtol=1.49012e-8, trace=None):
+              lambda0=1e-3, ftol=1.49012e-8, xtol=1.49012e-8, trace=None, accel=False):
     """orc.lm_dense -- the dense twin of the PRODUCT's Levenberg-Marquardt loop on the oracle's pinned
     (MinFunc, D_MinFunc) pair -- with the sparse Jacobian and a sparse LU in place of numpy.linalg.solve.  Same
     damping rules, acceptance test and stopping tests, statement for statement."""
@@ -263,11 +266,18 @@ def lm_sparse(P0, nbr, wt, source, edges, nn, c=(orc.C_FIT, orc.C_RIGID, orc.C_S
         accepted = False
         while not accepted and not out["info"]:
             delta = solver.solve(lam, d2, -grad)
+            dmodel = delta
+            if accel:   # the product's accelerated iteration, as in orc.lm_dense
+                fvv = f(x + delta) - 2.0 * r + f(x - delta)
+                out["nfev"] += 2
+                delta2 = solver.solve(lam, d2, -0.5 * (J.T @ fvv))
+                if float((delta2 * delta2 * d2).sum()) <= 0.5625 * float((delta * delta * d2).sum()):
+                    delta = delta + delta2
             xt = x + delta
             rt = f(xt)
             f2t = float(rt @ rt)
             out["nfev"] += 1
-            dn2, dg, xn2 = float((delta * delta * d2).sum()), float(delta @ grad), float((x * x * d2).sum())
+            dn2, dg, xn2 = float((dmodel * dmodel * d2).sum()), float(dmodel @ grad), float((x * x * d2).sum())
             pred, actred = lam * dn2 - dg, f2 - f2t
             ratio = actred / pred if pred > 0 else (1.0 if actred > 0 else -1.0)
             if trace is not None:

@@ -77,7 +77,7 @@ def main():
             errs["Jv"] = rel(nicp.jvp(P, w, v, edges, c, pv, compat=False).cpu().numpy(), J_o @ pv)
             errs["JTu"] = rel(nicp.jtvp(P, w, v, edges, c, pu, compat=False).cpu().numpy(), J_o.T @ pu)
             # one LM step (first trial, lam = 1e-3, D = column norms) against the refined dense solve
-            P1, st = nicp.solve(P, w, v, edges, nn, c, compat=False, opts=dict(max_lm_iters=1, cg_tol=1e-13))
+            P1, st = nicp.solve(P, w, v, edges, nn, c, compat=False, opts=dict(max_lm_iters=1, cg_tol=1e-13, accel=-1))
             col2 = (J_o * J_o).sum(0)
             H = J_o.T @ J_o + 1e-3 * np.diag(np.where(col2 > 0, col2, 1.0))
             g_o = J_o.T @ r_o
@@ -122,7 +122,7 @@ def main():
         errs["Jv"] = rel(nicp.jvp(P, w, v, edges, c, pv, compat=compat).cpu().numpy(), J_o @ pv)
         errs["JTu"] = rel(nicp.jtvp(P, w, v, edges, c, pu, compat=compat).cpu().numpy(), J_o.T @ pu)
         # one LM step of the product against the dense twin of its loop
-        P1, st = nicp.solve(P, w, v, edges, nn, c, compat=compat, opts=dict(max_lm_iters=1, cg_tol=1e-13))
+        P1, st = nicp.solve(P, w, v, edges, nn, c, compat=compat, opts=dict(max_lm_iters=1, cg_tol=1e-13, accel=-1))
         tr = []
         P1o = orc.lm_dense(P, nbr, wt, v, edges, nn, c, compat, steps=1, trace=tr)
         P1o = P1o[0] if isinstance(P1o, tuple) else P1o

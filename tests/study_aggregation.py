@@ -2,7 +2,8 @@
 equations with the shipped coarse spaces (12 global modes, 66 polynomial columns) against AGGREGATION spaces -- the 6 zero-
 stiffness modes restricted to aggregates of s Morton-consecutive vertices (+ the 6 global parameters), exact coarse solve.
 Uses the sparse oracle, so it lives with the tests (the only place allowed to import oracle/); a study tool, not collected:
-    python tests/study_aggregation.py 100 4e-8 1e-3 1024,256,64,16
+    python tests/study_aggregation.py 100 4e-8 1e-3 1024,256,64,16        (aggregate sizes)
+    python tests/study_aggregation.py 100 4e-8 1e-3 64 2,3,4              (instead: full polynomial spaces of these degrees)
 Results: profiles/r3_nicp_studies.txt, DESIGN.md section 3.3."""
 import sys,time; sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', 'oracle'))
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
@@ -87,8 +88,20 @@ def agg(size):
     m=(n+size-1)//size
     W=sp.coo_matrix((np.ones(n),(mo,np.arange(n)//size)),shape=(n,m))
     return W
+import itertools
+def monomials(deg):
+    cols=[]
+    for d in range(deg+1):
+        for ex in itertools.product(range(d+1),repeat=3):
+            if sum(ex)==d: cols.append(c[:,0]**ex[0]*c[:,1]**ex[1]*c[:,2]**ex[2])
+    return np.stack(cols,1)
 t=time.time()
 print("n",n,"lam",lam,"tol",tol,flush=True)
+if len(sys.argv)>5:
+    for deg in [int(a) for a in sys.argv[5].split(",")]:
+        W=monomials(deg)
+        print("poly degree %d (%d functions, %d cols):"%(deg,W.shape[1],W.shape[1]*6+6),pcg(coarse_from_weights(W)),"%.0fs"%(time.time()-t),flush=True)
+    sys.exit(0)
 print("plain 12:",pcg(coarse_from_weights(one)),"%.0fs"%(time.time()-t),flush=True)
 print("poly 66:",pcg(coarse_from_weights(poly)),"%.0fs"%(time.time()-t),flush=True)
 for size in [int(a) for a in sys.argv[4].split(",")]:

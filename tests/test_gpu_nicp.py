@@ -157,7 +157,7 @@ def test_solve_compat_vs_golden(mods, name):
 
 
 @pytest.mark.parametrize("name", ["nicp_step_24", "nicp_step_60", "nicp_row_20"])
-@pytest.mark.parametrize("compat", [True, False])
+@pytest.mark.parametrize("compat", [True, False, "accel"])
 @pytest.mark.parametrize("start", ["P0", "P_rand"])
 def test_lm_steps_match_dense_solves(mods, name, compat, start):
     """What IS determinate in the reference-as-coded mode: given the pinned pair (MinFunc, D_MinFunc), each
@@ -167,15 +167,19 @@ def test_lm_steps_match_dense_solves(mods, name, compat, start):
     reference's start P0 (R = I) and from a perturbed P (R != I: exercises Q6, rejected trials and the
     damping updates).  A sign or slot error in a compat-only branch of jp / jtu / block_diag that still
     lowered the energy would fail here."""
+    # "accel": the accelerated iteration (nicp_solve_opts::accel = 1: second-order correction of every step), which is the
+    # DEFAULT of the self-consistent mode, against the oracle's twin of it; True / False: the plain iteration (accel = -1)
+    accel = compat == "accel"
+    compat = compat is True
     g = golden(name)
     v, edges, nn, Ps = g["v"], g["edges"], g["nn"], g[start]
     nbr, wt = sparse_from_dense(g["w"])
     nic = mods["nicp"]
     w = nic.SparseWeights(nbr, wt, v.shape[1])
     for steps in (1, 4):
-        Pref, info = orc.lm_dense(Ps, nbr, wt, v, edges, nn, C, compat, steps=steps, ftol=0.0, xtol=0.0)
+        Pref, info = orc.lm_dense(Ps, nbr, wt, v, edges, nn, C, compat, steps=steps, ftol=0.0, xtol=0.0, accel=accel)
         P, st = nic.solve(Ps, w, v, edges, nn, C, compat=compat,
-                          opts=dict(max_lm_iters=steps, cg_tol=1e-13, ftol=0.0, xtol=0.0))
+                          opts=dict(max_lm_iters=steps, cg_tol=1e-13, ftol=0.0, xtol=0.0, accel=1 if accel else -1))
         d_ref, d_gpu = Pref - Ps, P.cpu().numpy() - Ps
         print(name, compat, start, steps, "ref", {k: info[k] for k in ("err0", "err", "nfev")}, "gpu", st,
               "max|d-dref|/max|dref|", np.abs(d_gpu - d_ref).max() / np.abs(d_ref).max())

@@ -44,7 +44,7 @@ def case_inputs(nx):
 
 
 @pytest.mark.parametrize("nx", [50, 100])
-@pytest.mark.parametrize("mode", ["compat", "corrected"])
+@pytest.mark.parametrize("mode", ["compat", "corrected", "accel"])
 @pytest.mark.parametrize("start", ["P0", "Ppert"])
 def test_lm_steps_on_large_meshes_match_sparse_direct_solves(nic, monkeypatch, nx, mode, start):
     for k in SWITCHES:                                      # the DEFAULT path: no switch may be set
@@ -68,11 +68,13 @@ def test_lm_steps_on_large_meshes_match_sparse_direct_solves(nic, monkeypatch, n
         # a step accepted only after the damping ran away (compat mode from a perturbed P: the trial step collapses and
         # accept / reject is decided by the rounding noise of the energy) is not a determinate quantity -- DESIGN.md
         # 'NICP solve parity'; such checkpoints are left out
+        # (modes: compat / corrected = the plain LM iteration, accel = the accelerated one that the self-consistent mode
+        # runs by default, each against lm_sparse in the same form)
         upto = np.nonzero(g[key + "_accepted"])[0][steps - 1]
         if g[key + "_lam"][:upto + 1].max() > 1e8:
             continue
         P, st = nic.solve(Ps, w, d["v"], d["edges"], d["nn"], C, compat=(mode == "compat"),
-                          opts=dict(max_lm_iters=steps, cg_tol=1e-13, ftol=0.0, xtol=0.0))
+                          opts=dict(max_lm_iters=steps, cg_tol=1e-13, ftol=0.0, xtol=0.0, accel=1 if mode == "accel" else -1))
         if n >= 1024:
             assert st["graph_launches"] > 0                 # it really was the graph-replay path
         delta = P.cpu().numpy() - Ps
