@@ -3553,7 +3553,6 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             if (int rc = cg_loop()) return rc;
             tick(4);  // CG iterations
             const int cg_first = hs.iters;
-            if (hs.iters > 400 && w.pb.M < coarse_switch_to) w.pb.M = coarse_switch_to;  // same decision on every rank (global counters)
             if (int rc = exchange(ctx, g, w, par, w.delta)) return rc;
             // ---- second-order correction of the step (accel, see the top of this function).  Buffers: d1 is kept in
             // w.x_trial once the two extra residuals are taken, J^T r'' goes through w.z (the next solve's start overwrites it)
@@ -3592,6 +3591,9 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 hipLaunchKernelGGL(axpby_kernel, dim3(nbp), dim3(NB), 0, st, 1.0, (const double *)w.x_trial, 1.0, geo_used ? (const double *)w.delta : (const double *)nullptr, w.delta, d.np);
                 hs.iters += cg_first;
             }
+            // a long first solve: richer coarse space from the next linear system on (only now -- the second-order solve
+            // above still ran with the coarse matrix of this one).  Same decision on every rank (global counters)
+            if (cg_first > 400 && w.pb.M < coarse_switch_to) w.pb.M = coarse_switch_to;
             // predicted reduction of |r|^2 : delta^T (lam D^2 delta - grad); with the second-order correction the model is
             // the first-order step's (Transtrum's gain ratio), which still sits in w.x_trial
             {
