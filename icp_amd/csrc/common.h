@@ -37,6 +37,7 @@ struct Scratch {
     size_t cap = 0;
 };
 
+constexpr size_t kSmallBytes = 8192;  // icp_ctx::small: RigidState + reduce buffer | find_transform scratch | the builds' statistics records
 constexpr int kMaxPartials = 2048;   // upper bound on blocks of any partial-sum reduction
 constexpr int kSumSlots = 16;        // doubles per block partial / per reduced vector
 
@@ -67,6 +68,7 @@ struct icp_ctx {
     // this device's address of kabsch.hip's file-scope scratch array (icp_find_transform_noalloc)
     double *noalloc_scratch = nullptr;
     void *pinned = nullptr;  // 1 KB of pinned host memory: asynchronous read-back of the grid statistics (grid.hip)
+    hipEvent_t stat_ev[2] = {nullptr, nullptr};  // "the statistics record of build slot 0 / 1 has reached the host"
 };
 
 namespace icp {
@@ -104,6 +106,7 @@ struct GridPending {
     int dim = 0, ns = 0;
     bool stable = false, robust = false, adaptive = false;
     void *host = nullptr;   // pinned copy of the statistics record
+    hipEvent_t ev = nullptr;  // recorded behind that copy: the second half waits for it, not for the whole stream
     Scratch *sa = nullptr, *sb = nullptr, *sc = nullptr, *sd = nullptr;
 };
 int grid_build_begin(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBuild &gb, Scratch &sa, Scratch &sb,

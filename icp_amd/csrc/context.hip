@@ -78,6 +78,8 @@ extern "C" int icp_ctx_destroy(icp_ctx *ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->side_ev) (void)hipEventDestroy(ctx->side_ev);
     if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
+    for (hipEvent_t ev : ctx->stat_ev)
+        if (ev) (void)hipEventDestroy(ev);
     delete ctx;
     return ICP_OK;
 }

@@ -38,8 +38,11 @@ struct BBox {
     double mn[3], mx[3];
     unsigned long long bad;
     double qlo[3], qhi[3];  // per-axis 1 % / 99 % order statistics of a fixed-stride sample (quantile_kernel)
-    double pairs[16];       // sample pairs sharing a cell of side ext / 2^(B - l), l = 0 .. B (occupancy_kernel)
+    // ordered sample pairs (i, j), self-pairs included, whose codes first share a cell at level l of the B-bit hierarchy
+    // (occupancy_kernel), spread over kPairSub sub-counters so that the blocks' atomics do not queue on one address
+    unsigned int pairs_u[14][4];
 };
+constexpr int kPairSub = 4;
 
 template <int DIM>
 __global__ __launch_bounds__(GB) void bbox_kernel(const double *__restrict__ p, int64_t n, double *__restrict__ partial) {
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(GB) void bbox_kernel(const double *__restrict__ p, 
 __global__ void bbox_final_kernel(const double *__restrict__ partial, int nb, BBox *__restrict__ out) {
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k >= 7) return;
+    if (threadIdx.x < 14 * kPairSub) (&out->pairs_u[0][0])[threadIdx.x] = 0u;   // occupancy_kernel adds into them
     double v = k < 3 ? __builtin_inf() : (k < 6 ? -__builtin_inf() : 0.0);
     for (int b = lane; b < nb; b += 64) {
         const double x = partial[(int64_t)b * 8 + k];
@@ -142,7 +146,6 @@ __device__ __forceinline__ void open_sides(const GridParams &gp, int a, int x, i
     if (x >= ncl - 1 && ((gp.open >> (2 * a + 1)) & 1)) gh = -__builtin_inf();
 }
 
-// Block a sorts the a-th coordinate of ns <= 4096 points taken at a fixed stride (bitonic network in LDS) and writes its
 // LDS written by some lanes of a wave and read by others of the same wave: the hardware keeps a wave's LDS operations
 // in order, this keeps the compiler from moving them across each other
 __device__ __forceinline__ void lds_wave_sync() {
@@ -151,43 +154,51 @@ __device__ __forceinline__ void lds_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Bitonic sort of kQuantSamples values in LDS by a 1024-thread block.  Thread t of a stage touches elements inside
-// the 128-element chunk of its wave's 64 consecutive pairs whenever the stride is at most 64, so only the 15 stages
-// with longer strides (and the stage before each of them) need the block barrier: the other 63 of the 78 stages order
-// their LDS traffic inside the wave (quantile_kernel 48 -> see DESIGN.md 3.1b; the block runs on one compute unit and
-// its barriers were its run time).
+// Sample statistics of a target build (robust extents, resolution from the data).  Rounds 1-2 sorted the sample twice
+// with a bitonic network in ONE block each (quantile_kernel 37 us, occupancy_kernel 81 us: both on the critical path of
+// a call's set-up, on one compute unit of 256).  Neither statistic needs an order: an order statistic is "the sample
+// that exactly k others precede", and the pair counts are sums over all pairs -- 4096^2 comparisons each, which the
+// whole chip does in a few microseconds.
 constexpr int kQuantSamples = 4096;
-template <typename T>
-__device__ __forceinline__ void bitonic_sort_lds(T *v) {
-    for (int size = 2; size <= kQuantSamples; size <<= 1)
-        for (int ls = 31 - __builtin_clz(size >> 1); ls >= 0; --ls) {   // stride 2^ls: shifts, no integer division --
-            const int str = 1 << ls;                                     // the block runs on ONE compute unit and its
-            for (int t = threadIdx.x; t < kQuantSamples / 2; t += blockDim.x) {   // instructions are its run time
-                const int lo = ((t >> ls) << (ls + 1)) + (t & (str - 1)), hi = lo + str;
-                const bool up = ((lo & size) == 0);
-                const T x = v[lo], y = v[hi];
-                if ((x > y) == up) {
-                    v[lo] = y;
-                    v[hi] = x;
-                }
-            }
-            if (str >= 128 || (str == 1 && size >= 128)) __syncthreads();
-            else lds_wave_sync();
-        }
-}
+constexpr int kQuantCand = 32;   // candidates per block of quantile_kernel (grid: dim x kQuantSamples / kQuantCand)
 
-// k-th smallest and k-th largest value: the quantiles that set the extents of the grid.  Deterministic.
-__global__ __launch_bounds__(1024) void quantile_kernel(const double *__restrict__ p, int64_t stride, int ns, int dim, int k,
-                                                        BBox *__restrict__ out) {
+// k-th smallest and k-th largest coordinate of the sample, per axis: the quantiles that set the extents of the grid.
+// Block (a, y): the 32 candidates 32y .. 32y+31 of axis a; thread (candidate c, part q) counts, over an eighth of the
+// sample, the values below v[c] and the values not above it; v[c] IS the k-th order statistic iff lt <= k < le.  Tied
+// candidates all qualify and all write the same value, so the result is what a sort would give, deterministically.
+__global__ __launch_bounds__(256) void quantile_kernel(const double *__restrict__ p, int64_t stride, int ns, int dim, int k,
+                                                       BBox *__restrict__ out) {
     __shared__ double v[kQuantSamples];
+    __shared__ int part[8][kQuantCand][2];
     const int a = blockIdx.x;
-    for (int i = threadIdx.x; i < kQuantSamples; i += blockDim.x)
-        v[i] = i < ns ? p[(int64_t)i * stride * dim + a] : __builtin_inf();
+    for (int i = threadIdx.x; i < kQuantSamples; i += 256)
+        v[i] = i < ns ? p[(int64_t)i * stride * dim + a] : __builtin_inf();   // (targets are finite, or the build is refused)
     __syncthreads();
-    bitonic_sort_lds(v);
-    if (threadIdx.x == 0) {
-        out->qlo[a] = v[k];
-        out->qhi[a] = v[ns - 1 - k];
+    const int cl = threadIdx.x & (kQuantCand - 1);
+    const int c = blockIdx.y * kQuantCand + cl;
+    const int q = threadIdx.x / kQuantCand;   // 8 parts of 512 samples
+    const double vc = v[c];
+    int lt = 0, le = 0;
+    const int j0 = q * (kQuantSamples / 8);
+#pragma unroll 8
+    for (int j = j0; j < j0 + kQuantSamples / 8; ++j) {
+        const double x = v[j];
+        lt += x < vc ? 1 : 0;
+        le += x <= vc ? 1 : 0;
+    }
+    part[q][cl][0] = lt;
+    part[q][cl][1] = le;
+    __syncthreads();
+    if (threadIdx.x < kQuantCand && c < ns) {
+        lt = 0;
+        le = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            lt += part[w][cl][0];
+            le += part[w][cl][1];
+        }
+        if (lt <= k && k < le) out->qlo[a] = vc;
+        if (lt <= ns - 1 - k && ns - 1 - k < le) out->qhi[a] = vc;
     }
 }
 
@@ -195,18 +206,21 @@ __global__ __launch_bounds__(1024) void quantile_kernel(const double *__restrict
 // the points fill space, not only on how many there are: a volume-filling cloud, a Gaussian and a scanned surface of
 // the same size want cells of different sizes (measured: 2^20 points, best finest level 6 / 7 / 8+ bits per axis).  The
 // density-weighted mean population of a cell is 1 + N * P(two random points share a cell), and that probability is
-// estimated here at EVERY level at once from the pairs of the sample: the samples' Morton codes at the finest
-// conceivable level (B bits per axis) are sorted, and two samples share a level-l cell iff their codes agree above
-// dim*l bits -- in sorted order those are runs.  pairs[l] = number of sample pairs in a common level-l cell (each
-// element counts at most 32 predecessors: beyond that the level is far too coarse anyway).
+// estimated here at EVERY level at once from the pairs of the sample: with the samples' Morton codes at the finest
+// conceivable level (B bits per axis), two samples share a level-l cell iff their codes agree above dim*l bits, i.e.
+// from level ceil(bitlength(a ^ b) / dim) upwards.  Block (x, y): rows 64x .. 64x+63 against the columns of quarter y,
+// each of its four waves 256 of them; pairs_u[l] += ordered pairs (self-pairs included: the host takes them out) whose
+// FIRST shared level is l.  (Round 2 sorted the codes and let every sample count at most 32 predecessors: the same
+// numbers wherever a cell holds at most 33 samples, i.e. at every level near the population the host looks for.)
 constexpr int kOccB3 = 9, kOccB2 = 13;
-__global__ __launch_bounds__(1024) void occupancy_kernel(const double *__restrict__ p, int64_t stride, int ns, int dim,
-                                                         double clip, BBox *__restrict__ io) {
-    __shared__ uint32_t code[kQuantSamples];
-    __shared__ unsigned int pairs[16];
+__global__ __launch_bounds__(256) void occupancy_kernel(const double *__restrict__ p, int64_t stride, int ns, int dim,
+                                                        double clip, BBox *__restrict__ io) {
+    __shared__ uint32_t rowc[64];
+    __shared__ uint32_t colc[kQuantSamples / 4];
+    __shared__ unsigned int tot[14];
     const int B = dim == 3 ? kOccB3 : kOccB2;
     double mn[3] = {0, 0, 0}, ext = 0.0;
-    for (int a = 0; a < dim; ++a) {  // the extents grid_build_into will choose (same arithmetic)
+    for (int a = 0; a < dim; ++a) {  // the extents grid_build_finish will choose (same arithmetic)
         double lo = io->mn[a], hi = io->mx[a];
         const double wdt = io->qhi[a] - io->qlo[a];
         if (wdt > 0.0 && wdt < __builtin_inf()) {
@@ -220,46 +234,51 @@ __global__ __launch_bounds__(1024) void occupancy_kernel(const double *__restric
     if (!(ext > 0.0)) ext = 1.0;
     const double inv_h = 1.0 / (ext / (double)(1 << B) * (1.0 + 0x1p-30));
     const int top = (1 << B) - 1;
-    if (threadIdx.x < 16) pairs[threadIdx.x] = 0u;
-    for (int i = threadIdx.x; i < kQuantSamples; i += blockDim.x) {
-        uint32_t c = 0xffffffffu;
-        if (i < ns) {
-            int cell[3] = {0, 0, 0};
-            for (int a = 0; a < dim; ++a) {
-                const double f = (p[(int64_t)i * stride * dim + a] - mn[a]) * inv_h;
-                cell[a] = f >= 0.0 ? (f < (double)top ? (int)f : top) : 0;
-            }
-            c = dim == 3 ? (spread3(cell[0]) | (spread3(cell[1]) << 1) | (spread3(cell[2]) << 2)) : (spread2(cell[0]) | (spread2(cell[1]) << 1));
+    auto code_of = [&](int i) -> uint32_t {
+        int cell[3] = {0, 0, 0};
+        for (int a = 0; a < dim; ++a) {
+            const double f = (p[(int64_t)i * stride * dim + a] - mn[a]) * inv_h;
+            cell[a] = f >= 0.0 ? (f < (double)top ? (int)f : top) : 0;
         }
-        code[i] = c;
-    }
+        return dim == 3 ? (spread3(cell[0]) | (spread3(cell[1]) << 1) | (spread3(cell[2]) << 2)) : (spread2(cell[0]) | (spread2(cell[1]) << 1));
+    };
+    constexpr int NC = kQuantSamples / 4;   // columns of a block
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * NC;
+    if (threadIdx.x < 14) tot[threadIdx.x] = 0u;
+    if (threadIdx.x < 64) rowc[threadIdx.x] = r0 + threadIdx.x < ns ? code_of(r0 + threadIdx.x) : 0u;
+    for (int j = threadIdx.x; j < NC; j += 256) colc[j] = c0 + j < ns ? code_of(c0 + j) : 0u;
     __syncthreads();
-    bitonic_sort_lds(code);
-    // one walk over the (at most 32) predecessors of every sample serves all levels: two codes share a level-l cell iff
-    // they agree above dim*l bits, i.e. from level ceil(bitlength(a ^ b) / dim) upwards
-    // (per thread at most 4 x 32 pairs: the counts per first-shared level fit 8-bit fields of two 64-bit words; the
-    //  block runs on ONE compute unit, so the instructions of this walk are its run time)
-    unsigned long long h0 = 0ull, h1 = 0ull;
-    for (int i = threadIdx.x; i < ns; i += blockDim.x) {
-        const uint32_t ci = code[i];
-        for (int d = 1; d <= 32 && i - d >= 0; ++d) {
-            const uint32_t x = ci ^ code[i - d];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t ci = rowc[lane];
+    const bool row_ok = r0 + lane < ns;
+    const int jb = wv * (NC / 4);
+    int jn = ns - (c0 + jb);               // columns of this wave that are real samples (wave-uniform)
+    jn = jn < 0 ? 0 : (jn > NC / 4 ? NC / 4 : jn);
+    unsigned int cnt[14];
+#pragma unroll
+    for (int l = 0; l < 14; ++l) cnt[l] = 0u;
+    for (int jj = 0; jj < jn; jj += 128) {   // at most 128 pairs per flush: the 8-bit fields cannot overflow
+        unsigned long long h0 = 0ull, h1 = 0ull;
+        const int je = jj + 128 < jn ? jj + 128 : jn;
+        for (int j = jj; j < je; ++j) {
+            const uint32_t x = ci ^ colc[jb + j];   // (every lane reads the same word: a broadcast)
             const int nb = x ? 32 - __clz((int)x) : 0;
             const int lmin = dim == 3 ? (nb + 2) / 3 : (nb + 1) >> 1;
             if (lmin < 8) h0 += 1ull << (8 * lmin);
             else h1 += 1ull << (8 * (lmin - 8));
         }
+#pragma unroll
+        for (int l = 0; l < 14; ++l) cnt[l] += (unsigned int)(((l < 8 ? h0 : h1) >> (8 * (l & 7))) & 0xffull);
     }
-    unsigned int run = 0u;  // pairs[l] = pairs whose first shared level is <= l
 #pragma unroll
     for (int l = 0; l < 14; ++l) {
-        run += (unsigned int)(((l < 8 ? h0 : h1) >> (8 * (l & 7))) & 0xffull);
-        unsigned int v = run;
+        unsigned int v = row_ok ? cnt[l] : 0u;
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&pairs[l], v);
+        if (lane == 0 && v) atomicAdd(&tot[l], v);
     }
     __syncthreads();
-    if (threadIdx.x <= B) io->pairs[threadIdx.x] = (double)pairs[threadIdx.x];
+    if (threadIdx.x <= B && threadIdx.x < 14 && tot[threadIdx.x])
+        atomicAdd(&io->pairs_u[threadIdx.x][(blockIdx.x + blockIdx.y) & (kPairSub - 1)], tot[threadIdx.x]);
 }
 
 template <int DIM>
@@ -275,6 +294,20 @@ __global__ __launch_bounds__(GB) void cell_count_kernel(const double *__restrict
     const uint32_t code = morton<DIM>(c);
     code_out[i] = code;
     atomicAdd(&count[code], 1u);
+}
+
+// the cell codes alone (a build that only wants the Morton ORDER of its points: no cell ranges, no counters)
+template <int DIM>
+__global__ __launch_bounds__(GB) void cell_code_kernel(const double *__restrict__ pts, int64_t m, GridParams gp,
+                                                      uint32_t *__restrict__ code_out) {
+    const int64_t i = (int64_t)blockIdx.x * GB + threadIdx.x;
+    if (i >= m) return;
+    double p[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) p[a] = pts[i * DIM + a];
+    int c[DIM];
+    cell_of<DIM>(p, gp, c);
+    code_out[i] = morton<DIM>(c);
 }
 
 // exclusive scan of `count[0..len)` in three passes; block sums in `bsum`
@@ -370,6 +403,17 @@ __global__ __launch_bounds__(GB) void scatter_kernel(const double *__restrict__ 
 #pragma unroll
     for (int a = 0; a < DIM; ++a) spts[(int64_t)pos * DIM + a] = tgt[i * DIM + a];
     code[i] = (uint32_t)pos;  // the cell code is spent: the array becomes the inverse permutation (GridBuild::inv)
+}
+
+// order-only build: the points in Morton order, nothing else
+template <int DIM>
+__global__ __launch_bounds__(GB) void gather_order_kernel(const double *__restrict__ pts, int64_t m, double *__restrict__ spts,
+                                                         const int32_t *__restrict__ sidx) {
+    const int64_t pos = (int64_t)blockIdx.x * GB + threadIdx.x;
+    if (pos >= m) return;
+    const int64_t i = sidx[pos];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) spts[pos * DIM + a] = pts[i * DIM + a];
 }
 
 // The same scatter without the sort, for grids that are only SEARCHED (targets): a point takes the next free slot of
@@ -1502,12 +1546,12 @@ int grid_build_begin(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBu
     hipStream_t st = ctx->stream;
     gb.usable = false;
     if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
-    if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
+    if (int rc = ensure(ctx, ctx->small, kSmallBytes)) return rc;
     if (!ctx->pinned) ICP_HIP_CHECK(hipHostMalloc(&ctx->pinned, 1024, hipHostMallocDefault));
-    static_assert(sizeof(BBox) <= 256 && 440 * 8 + sizeof(BBox) <= 4096 && 1024 * 8 * 2 <= kMaxPartials * kSumSlots,
+    static_assert(sizeof(BBox) <= 512 && 768 * 8 + sizeof(BBox) <= kSmallBytes && 1024 * 8 * 2 <= kMaxPartials * kSumSlots,
                   "scratch of the two concurrent builds overlaps");
     double *part = (double *)ctx->partials.ptr + (stable ? 1024 * 8 : 0);
-    BBox *dbox = (BBox *)((double *)ctx->small.ptr + (stable ? 440 : 400));
+    BBox *dbox = (BBox *)((double *)ctx->small.ptr + (stable ? 768 : 512));
     int nb = (int)((m + GB - 1) / GB);
     if (nb > 1024) nb = 1024;
     if (dim == 3) hipLaunchKernelGGL(bbox_kernel<3>, dim3(nb), dim3(GB), 0, st, tgt, m, part);
@@ -1524,12 +1568,16 @@ int grid_build_begin(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBu
     const int ns = (int)std::min<int64_t>(kQuantSamples, m);
     const bool robust = clip >= 0.0 && ns >= 64 && !stable;  // (a sorted SOURCE only needs an order: any extents do)
     if (robust)  // (same stream, after bbox_final_kernel: it adds its six numbers to the same record)
-        hipLaunchKernelGGL(quantile_kernel, dim3(dim), dim3(1024), 0, st, tgt, m / ns, ns, dim, std::max(1, ns / 100), dbox);
+        hipLaunchKernelGGL(quantile_kernel, dim3(dim, kQuantSamples / kQuantCand), dim3(256), 0, st, tgt, m / ns, ns, dim, std::max(1, ns / 100), dbox);
     const bool adaptive = robust && env_bits() <= 0 && grid_occ_target() > 0.0;
-    if (adaptive) hipLaunchKernelGGL(occupancy_kernel, dim3(1), dim3(1024), 0, st, tgt, m / ns, ns, dim, clip, dbox);
+    if (adaptive) hipLaunchKernelGGL(occupancy_kernel, dim3(kQuantSamples / 64, 4), dim3(256), 0, st, tgt, m / ns, ns, dim, clip, dbox);
     ICP_HIP_CHECK(hipGetLastError());
     void *host = (char *)ctx->pinned + (stable ? 512 : 0);
     ICP_HIP_CHECK(hipMemcpyAsync(host, dbox, sizeof(BBox), hipMemcpyDeviceToHost, st));
+    hipEvent_t &ev = ctx->stat_ev[stable ? 1 : 0];
+    if (!ev) ICP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    ICP_HIP_CHECK(hipEventRecord(ev, st));   // (the caller may queue unrelated work behind the copy: build_grids in kabsch.hip)
+    pend.ev = ev;
     pend.pts = tgt;
     pend.m = m;
     pend.dim = dim;
@@ -1555,7 +1603,7 @@ int grid_build_finish(icp_ctx *ctx, const GridPending &pend, GridBuild &gb) {
     const bool stable = pend.stable, robust = pend.robust, adaptive = pend.adaptive;
     Scratch &sa = *pend.sa, &sb = *pend.sb, &sc = *pend.sc, &sd = *pend.sd;
     const double clip = grid_clip(), occ_target = grid_occ_target();
-    ICP_HIP_CHECK(hipStreamSynchronize(st));
+    ICP_HIP_CHECK(hipEventSynchronize(pend.ev));
     BBox hb;
     std::memcpy(&hb, pend.host, sizeof(BBox));
     if (hb.bad) return ICP_OK;  // NaN / inf in the target: caller uses the brute-force scan
@@ -1594,7 +1642,12 @@ int grid_build_finish(icp_ctx *ctx, const GridPending &pend, GridBuild &gb) {
         const double denom = 0.5 * (double)ns * (double)(ns - 1);
         double best_d = __builtin_inf();
         for (int b = 1; b <= maxbits; ++b) {
-            const double occ = 1.0 + (double)m * hb.pairs[B - b] / denom;
+            // unordered pairs sharing a cell at hierarchy level B - b = (ordered pairs whose first shared level is <= that,
+            // minus the ns self-pairs, which share every level) / 2
+            double ordered = 0.0;
+            for (int l = 0; l <= B - b; ++l)
+                for (int u = 0; u < kPairSub; ++u) ordered += (double)hb.pairs_u[l][u];
+            const double occ = 1.0 + (double)m * (0.5 * (ordered - (double)ns)) / denom;
             const double d = std::fabs(std::log(occ / occ_target));
             if (d <= best_d) {   // ties: the finer level
                 best_d = d;
@@ -1619,6 +1672,30 @@ int grid_build_finish(icp_ctx *ctx, const GridPending &pend, GridBuild &gb) {
     gp.inv_h = 1.0 / gp.h;
     const int64_t ncell = 1ll << (dim * bits);
     const int64_t nsb = (ncell + (int64_t)GB * SCAN_ITEMS - 1) / ((int64_t)GB * SCAN_ITEMS);
+    if (stable) {
+        // A build that only wants the ORDER of its points (a sorted source, icp_morton_sort): codes -> stable sort ->
+        // gather.  No cell counters (a million device-wide atomics: 53 us), no scan, no records: set-up of a rigid run
+        // 0.54 -> see DESIGN.md 3.1b.  start / recs / inv stay null: such a build is never searched.
+        if (int rc = ensure(ctx, sa, (size_t)m * dim * sizeof(double) + 64)) return rc;
+        if (int rc = ensure(ctx, sb, (size_t)m * sizeof(int32_t) * 4)) return rc;     // sorted idx | codes | sorted codes | 0..m-1
+        gb.spts = (double *)sa.ptr;
+        gb.sidx = (int32_t *)sb.ptr;
+        gb.recs = nullptr;
+        gb.start = nullptr;
+        gb.inv = nullptr;
+        uint32_t *oc = (uint32_t *)sb.ptr + m;
+        const unsigned ob = (unsigned)((m + GB - 1) / GB);
+        if (dim == 3) hipLaunchKernelGGL(cell_code_kernel<3>, dim3(ob), dim3(GB), 0, st, tgt, m, gp, oc);
+        else hipLaunchKernelGGL(cell_code_kernel<2>, dim3(ob), dim3(GB), 0, st, tgt, m, gp, oc);
+        if (int rc = stable_sort_codes(ctx, ctx->sort_tmp, oc, oc + m, (int32_t *)(oc + 2 * m), gb.sidx, m, dim * bits)) return rc;
+        if (dim == 3) hipLaunchKernelGGL(gather_order_kernel<3>, dim3(ob), dim3(GB), 0, st, tgt, m, gb.spts, (const int32_t *)gb.sidx);
+        else hipLaunchKernelGGL(gather_order_kernel<2>, dim3(ob), dim3(GB), 0, st, tgt, m, gb.spts, (const int32_t *)gb.sidx);
+        ICP_HIP_CHECK(hipGetLastError());
+        gb.gp = gp;
+        gb.m = m;
+        gb.usable = true;
+        return ICP_OK;
+    }
     if (int rc = ensure(ctx, sa, (size_t)m * (dim + 4) * sizeof(double) + 64 + kRecPad * 32)) return rc;   // sorted points | 32-byte records (+ pad)
     if (int rc = ensure(ctx, sb, (size_t)m * sizeof(int32_t) * 4)) return rc;     // sorted idx | codes | sorted codes | 0..m-1
     if (int rc = ensure(ctx, sc, (size_t)(ncell + 64) * sizeof(uint32_t) * 2)) return rc;  // start | count/fill
@@ -1640,9 +1717,9 @@ int grid_build_finish(icp_ctx *ctx, const GridPending &pend, GridBuild &gb) {
     static const bool force_stable = getenv("ICP_GRID_STABLE") && atoi(getenv("ICP_GRID_STABLE")) != 0;
     // (beyond a few million points the scattered 56-byte writes of the unordered fill cost more than sort + gather:
     //  2^24 points 1.76 ms against 0.25 + 0.83; 2^20 points 68 us against 160 + 43)
-    if (stable || force_stable || m > ((int64_t)1 << 22)) {
+    if (force_stable || m > ((int64_t)1 << 22)) {
         // (a sorted source and a large target are built on two streams at once by icp_rigid_run: separate sort storage)
-        if (int rc = stable_sort_codes(ctx, stable ? ctx->sort_tmp : ctx->sort_tmp_tgt, codes, codes + m, (int32_t *)(codes + 2 * m),
+        if (int rc = stable_sort_codes(ctx, ctx->sort_tmp_tgt, codes, codes + m, (int32_t *)(codes + 2 * m),
                                        gb.sidx, m, dim * bits))
             return rc;
         if (dim == 3) hipLaunchKernelGGL(scatter_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, gb.spts, (const int32_t *)gb.sidx, (double4 *)gb.recs);

@@ -574,7 +574,7 @@ extern "C" int icp_distance_sum(icp_ctx *ctx, const double *a, const double *b, 
 extern "C" int icp_column_sums(icp_ctx *ctx, const double *a, int64_t n, int dim, double *out_dev) {
     ICP_COMMON_ARGS(ctx, dim);
     ICP_REQUIRE(a && out_dev && n > 0, "bad argument");
-    if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
+    if (int rc = ensure(ctx, ctx->small, kSmallBytes)) return rc;
     double *tmp = (double *)ctx->small.ptr + 256;
     if (int rc = column_sums(ctx, a, n, dim, tmp, 0)) return rc;
     ICP_HIP_CHECK(hipMemcpyAsync(out_dev, tmp, sizeof(double) * dim, hipMemcpyDeviceToDevice, ctx->stream));
@@ -585,7 +585,7 @@ extern "C" int icp_find_transform(icp_ctx *ctx, const double *src, const double 
                                   double *R_out_dev, double *t_out_dev) {
     ICP_COMMON_ARGS(ctx, dim);
     ICP_REQUIRE(src && nn && R_out_dev && t_out_dev && n > 0, "bad argument");
-    if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
+    if (int rc = ensure(ctx, ctx->small, kSmallBytes)) return rc;
     double *base = (double *)ctx->small.ptr + 256;
     double *cs = base + 16, *ct = base + 32, *sums = base + 48;
     // pass 1: the two column means (icp_3d.py:69,71); pass 2: cross-covariance about them
@@ -673,9 +673,12 @@ extern "C" int icp_shard_apply_err(icp_ctx *ctx, const double *src, const double
 // target's statistics kernels -- single-block sorts of a sample -- and its read-back happen on the main stream;
 // the main stream waits for the side stream at the end.  2^20 x 2^20: set-up 0.78 -> see DESIGN.md 3.1b.
 namespace icp {
+template <typename Between>
 static int build_grids(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim, unsigned flags,
-                       GridBuild &grid, GridBuild &qsort) {
-    if (!grid_worthwhile(n, m, flags)) return ICP_OK;
+                       GridBuild &grid, GridBuild &qsort, Between between) {
+    // `between`: work of the caller that depends on neither structure (the rigid loop's two means), enqueued on the main
+    // stream behind the target's statistics kernels: it runs while the host waits for the read-backs and enqueues the sorts
+    if (!grid_worthwhile(n, m, flags)) return between();
     const bool sort_source = n >= 32768;
     bool side_ok = sort_source;
     if (side_ok && !ctx->side && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) side_ok = false;
@@ -691,6 +694,9 @@ static int build_grids(icp_ctx *ctx, const double *src, int64_t n, const double 
         if (int rc = grid_build_begin(ctx, tgt, m, dim, grid, ctx->grid_a, ctx->grid_b, ctx->grid_c, ctx->grid_d, false, pt)) return rc;
         ctx->stream = ctx->side;
         int rc = grid_build_begin(ctx, src, n, dim, qsort, ctx->sort_a, ctx->sort_b, ctx->sort_c, ctx->sort_d, true, ps);
+        ctx->stream = main_stream;
+        if (!rc) rc = between();
+        ctx->stream = ctx->side;
         if (!rc) rc = grid_build_finish(ctx, ps, qsort);
         ctx->stream = main_stream;
         if (rc) return rc;
@@ -699,7 +705,12 @@ static int build_grids(icp_ctx *ctx, const double *src, int64_t n, const double 
         ICP_HIP_CHECK(hipStreamWaitEvent(main_stream, ctx->side_ev, 0));
         return ICP_OK;
     }
-    if (int rc = grid_build(ctx, tgt, m, dim, grid)) return rc;
+    {
+        GridPending pt;
+        if (int rc = grid_build_begin(ctx, tgt, m, dim, grid, ctx->grid_a, ctx->grid_b, ctx->grid_c, ctx->grid_d, false, pt)) return rc;
+        if (int rc = between()) return rc;
+        if (int rc = grid_build_finish(ctx, pt, grid)) return rc;
+    }
     if (sort_source && grid.usable) {
         if (int rc = grid_build(ctx, src, n, dim, qsort, 1)) return rc;
     }
@@ -832,6 +843,43 @@ __global__ __launch_bounds__(RB) void dist_err_kernel(const double *__restrict__
     }
     if (tid == 0) st->err = red[0];
 }
+// One rank: dist_err_kernel + dist_last_pack_kernel + dist_last_step_kernel + rigid_finish_kernel in one launch (the tail
+// of a call was six dependent launches; same sums in the same order)
+__global__ __launch_bounds__(RB) void rigid_tail_kernel(const double *__restrict__ partial, int nb, RigidState *st,
+                                                        double *__restrict__ err_hist, int dim, double *__restrict__ T,
+                                                        int32_t *__restrict__ iters_out) {
+    __shared__ double red[RB];
+    const int tid = threadIdx.x;
+    const int done = st->done;
+    if (!done) {
+        double v = 0.0;
+        for (int b = tid; b < nb; b += RB) v += partial[(int64_t)b * kSumSlots];
+        red[tid] = v;
+        __syncthreads();
+        for (int o = RB / 2; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+    }
+    if (tid != 0) return;
+    int iters = st->iters;
+    if (!done) {
+        const double e = red[0];
+        st->err = e;
+        if (err_hist) err_hist[iters] = e;
+        st->err_prev = e;
+        iters += 1;
+        st->iters = iters;
+    }
+    const int d1 = dim + 1;
+    for (int a = 0; a < d1; ++a)
+        for (int b = 0; b < d1; ++b) T[a * d1 + b] = a == b ? 1.0 : 0.0;
+    for (int a = 0; a < dim; ++a) {
+        for (int b = 0; b < dim; ++b) T[a * d1 + b] = st->R[a * dim + b];
+        T[dim * d1 + a] = st->t[a];
+    }
+    if (iters_out) *iters_out = iters;
+}
 __global__ void dist_last_pack_kernel(const RigidState *st, double *__restrict__ buf) { buf[0] = st->done ? 0.0 : st->err; }
 __global__ void dist_last_step_kernel(const double *__restrict__ buf, RigidState *st, double *__restrict__ err_hist) {
     if (st->done) return;
@@ -874,7 +922,7 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
                       int max_iter, int use_tol, unsigned flags, double *T_out_dev, double *err_hist_dev,
                       int32_t *iters_out_dev, int32_t *idx_out, const icp_comm *comm) {
     const bool dist = comm_active(comm);  // every sum goes through the (all-)reduce buffer
-    if (int rc = ensure(ctx, ctx->small, 4096)) return rc;
+    if (int rc = ensure(ctx, ctx->small, kSmallBytes)) return rc;
     if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
     if (int rc = ensure(ctx, ctx->work_d, (size_t)n * sizeof(int32_t) * 2)) return rc;
     // the target never changes inside the loop: build its search grid once.  With the grid, put the source into
@@ -886,7 +934,31 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
     static const bool timing = getenv("ICP_RIGID_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tt0 = timing ? now() : 0.0;
-    if (int rc = build_grids(ctx, src, n, tgt, m, dim, flags, grid, qsort)) return rc;
+    RigidState *st = (RigidState *)ctx->small.ptr;
+    // a single rank needs no buffer from the caller: the 17 doubles live behind the RigidState block
+    double *buf = dist ? comm->reduce_buf_dev : (double *)ctx->small.ptr + 128;
+    static_assert(sizeof(RigidState) <= 128 * sizeof(double), "RigidState overlaps the local reduce buffer");
+    double *part = (double *)ctx->partials.ptr;
+    // The two means depend on neither the grid nor the Morton order, so they are enqueued between the halves of the
+    // builds (behind the target's statistics kernels on the main stream) and run while the host waits for the
+    // read-backs: 37 us off the critical path of a call.  Global mean of the ORIGINAL source rows (Q1) from (all-reduced)
+    // column sums; the target is replicated, its mean is local.  (Their block partials, at most 512 rows, end below the
+    // region the source's bounding-box kernels use on the side stream: grid_build_begin.)
+    const double *src_rows = src;
+    auto enqueue_means = [&]() -> int {
+        hipStream_t s = ctx->stream;
+        hipLaunchKernelGGL(rigid_init_kernel, dim3(1), dim3(1), 0, s, st);
+        const int nb = nblocks_for(n);
+        static_assert(kRowBlocksMax * kSumSlots <= 1024 * 8, "column-sum partials reach into the side stream's bounding-box partials");
+        if (dim == 3) hipLaunchKernelGGL(column_sums_kernel<3>, dim3(nb), dim3(RB), 0, s, src_rows, n, part);
+        else hipLaunchKernelGGL(column_sums_kernel<2>, dim3(nb), dim3(RB), 0, s, src_rows, n, part);
+        hipLaunchKernelGGL(dist_pack_means_kernel, dim3(1), dim3(RB), 0, s, (const double *)part, nb, buf);
+        ICP_HIP_CHECK(hipGetLastError());
+        if (int rc = comm_allreduce(ctx, comm, 4)) return rc;
+        hipLaunchKernelGGL(dist_means_kernel, dim3(1), dim3(64), 0, s, (const double *)buf, dim, st);
+        return column_sums(ctx, tgt, m, dim, st->ct, 1);
+    };
+    if (int rc = build_grids(ctx, src, n, tgt, m, dim, flags, grid, qsort, enqueue_means)) return rc;
     if (timing) {
         const double t1 = now();
         (void)hipStreamSynchronize(ctx->stream);
@@ -909,29 +981,13 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
     } else if (int rc = ensure(ctx, ctx->err_part, (size_t)(2 * ((n + 255) / 256) + 16) * sizeof(double))) {
         return rc;   // (an upper bound of the search's padded block count: no reallocation inside the loop)
     }
-    RigidState *st = (RigidState *)ctx->small.ptr;
-    // a single rank needs no buffer from the caller: the 17 doubles live behind the RigidState block
-    double *buf = dist ? comm->reduce_buf_dev : (double *)ctx->small.ptr + 128;
-    static_assert(sizeof(RigidState) <= 128 * sizeof(double), "RigidState overlaps the local reduce buffer");
-    double *part = (double *)ctx->partials.ptr;
     int32_t *ib[2] = {(int32_t *)ctx->work_d.ptr, (int32_t *)ctx->work_d.ptr + n};
     hipStream_t s = ctx->stream;
-    hipLaunchKernelGGL(rigid_init_kernel, dim3(1), dim3(1), 0, s, st);
-    // global mean of the ORIGINAL source (Q1) from (all-reduced) column sums; the target is replicated, its mean is local
-    {
-        const int nb = nblocks_for(n);
-        if (dim == 3) hipLaunchKernelGGL(column_sums_kernel<3>, dim3(nb), dim3(RB), 0, s, src, n, part);
-        else hipLaunchKernelGGL(column_sums_kernel<2>, dim3(nb), dim3(RB), 0, s, src, n, part);
-        hipLaunchKernelGGL(dist_pack_means_kernel, dim3(1), dim3(RB), 0, s, (const double *)part, nb, buf);
-        ICP_HIP_CHECK(hipGetLastError());
-        if (int rc = comm_allreduce(ctx, comm, 4)) return rc;
-        hipLaunchKernelGGL(dist_means_kernel, dim3(1), dim3(64), 0, s, (const double *)buf, dim, st);
-    }
-    if (int rc = column_sums(ctx, tgt, m, dim, st->ct, 1)) return rc;
     if (ss) ICP_HIP_CHECK(hipMemcpyAsync(ss, src, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToDevice, s));  // icp_3d.py:104
     const int32_t *done = &st->done;
     const double *tgt_rows = pos ? grid.spts : tgt;
     flags = (flags & ~(unsigned)(ICP_HINT_IDX | ICP_NO_FUSE)) | (pos ? ICP_INTERNAL_POS : 0u);
+    int tail_nb = 0;
     for (int it = 0; it < max_iter; ++it) {
         int32_t *idx = ib[it & 1];
         const int first = it == 0 ? 1 : 0;
@@ -957,19 +1013,26 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
         ICP_HIP_CHECK(hipGetLastError());
         if (!fused || it == max_iter - 1) {   // (fused: only the last iteration's error needs a pass of its own)
             if (int rc = apply_err(ctx, 1, src, tgt_rows, idx, n, dim, st->R, st->t, ss, st->sums, done, &nb)) return rc;
-            hipLaunchKernelGGL(dist_err_kernel, dim3(1), dim3(RB), 0, s, (const double *)part, nb, st);
-            ICP_HIP_CHECK(hipGetLastError());
+            tail_nb = nb;
+            if (dist || it != max_iter - 1) {   // (one rank: the last iteration's error is summed by rigid_tail_kernel)
+                hipLaunchKernelGGL(dist_err_kernel, dim3(1), dim3(RB), 0, s, (const double *)part, nb, st);
+                ICP_HIP_CHECK(hipGetLastError());
+            }
         }
     }
-    hipLaunchKernelGGL(dist_last_pack_kernel, dim3(1), dim3(1), 0, s, (const RigidState *)st, buf);
-    ICP_HIP_CHECK(hipGetLastError());
-    if (int rc = comm_allreduce(ctx, comm, 1)) return rc;
-    hipLaunchKernelGGL(dist_last_step_kernel, dim3(1), dim3(1), 0, s, (const double *)buf, st, err_hist_dev);
+    if (dist) {
+        hipLaunchKernelGGL(dist_last_pack_kernel, dim3(1), dim3(1), 0, s, (const RigidState *)st, buf);
+        ICP_HIP_CHECK(hipGetLastError());
+        if (int rc = comm_allreduce(ctx, comm, 1)) return rc;
+        hipLaunchKernelGGL(dist_last_step_kernel, dim3(1), dim3(1), 0, s, (const double *)buf, st, err_hist_dev);
+    } else {   // (before the un-sorting, which picks the correspondence buffer by the final iteration count)
+        hipLaunchKernelGGL(rigid_tail_kernel, dim3(1), dim3(RB), 0, s, (const double *)part, tail_nb, st, err_hist_dev, dim, T_out_dev, iters_out_dev);
+    }
     if (idx_out)
         hipLaunchKernelGGL(dist_unsort_idx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int32_t *)ib[0],
                            (const int32_t *)ib[1], (const RigidState *)st, order,
                            pos ? (const int32_t *)grid.sidx : (const int32_t *)nullptr, n, idx_out);
-    hipLaunchKernelGGL(rigid_finish_kernel, dim3(1), dim3(1), 0, s, (const RigidState *)st, dim, T_out_dev, iters_out_dev);
+    if (dist) hipLaunchKernelGGL(rigid_finish_kernel, dim3(1), dim3(1), 0, s, (const RigidState *)st, dim, T_out_dev, iters_out_dev);
     ICP_HIP_CHECK(hipGetLastError());
     if (timing) {
         const double t1 = now();
