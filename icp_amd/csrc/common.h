@@ -67,7 +67,7 @@ struct icp_ctx {
     hipEvent_t order_ev = nullptr;  // icp_ctx_set_stream: orders a new stream after the work queued on the previous one
     // this device's address of kabsch.hip's file-scope scratch array (icp_find_transform_noalloc)
     double *noalloc_scratch = nullptr;
-    void *pinned = nullptr;  // 1 KB of pinned host memory: asynchronous read-back of the grid statistics (grid.hip)
+    void *pinned = nullptr;  // 4 KB of pinned host memory: asynchronous read-back of the grid statistics (grid.hip)
     hipEvent_t stat_ev[2] = {nullptr, nullptr};  // "the statistics record of build slot 0 / 1 has reached the host"
 };
 

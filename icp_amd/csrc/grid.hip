@@ -40,12 +40,21 @@ struct BBox {
     double qlo[3], qhi[3];  // per-axis 1 % / 99 % order statistics of a fixed-stride sample (quantile_kernel)
     // ordered sample pairs (i, j), self-pairs included, whose codes first share a cell at level l of the B-bit hierarchy
     // (occupancy_kernel), spread over kPairSub sub-counters so that the blocks' atomics do not queue on one address
-    unsigned int pairs_u[14][4];
+    unsigned int pairs_u[14][8];
 };
-constexpr int kPairSub = 4;
+constexpr int kPairSub = 8;
 
+// Its first 4096 / GB blocks also gather the fixed-stride sample of the statistics kernels into a compact per-axis array
+// (samp[a * 4096 + i], +inf beyond ns; null: no sample wanted): 384 + 1024 blocks read it, and read straight from the
+// cloud every one of them touched 4096 cache lines for 4096 numbers.
 template <int DIM>
-__global__ __launch_bounds__(GB) void bbox_kernel(const double *__restrict__ p, int64_t n, double *__restrict__ partial) {
+__global__ __launch_bounds__(GB) void bbox_kernel(const double *__restrict__ p, int64_t n, double *__restrict__ partial,
+                                                  int64_t stride, int ns, double *__restrict__ samp) {
+    if (samp && blockIdx.x < 4096 / GB) {
+        const int i = blockIdx.x * GB + threadIdx.x;
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) samp[a * 4096 + i] = i < ns ? p[(int64_t)i * stride * DIM + a] : __builtin_inf();
+    }
     double mn[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
     double mx[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
     double bad = 0.0;
@@ -166,13 +175,11 @@ constexpr int kQuantCand = 32;   // candidates per block of quantile_kernel (gri
 // Block (a, y): the 32 candidates 32y .. 32y+31 of axis a; thread (candidate c, part q) counts, over an eighth of the
 // sample, the values below v[c] and the values not above it; v[c] IS the k-th order statistic iff lt <= k < le.  Tied
 // candidates all qualify and all write the same value, so the result is what a sort would give, deterministically.
-__global__ __launch_bounds__(256) void quantile_kernel(const double *__restrict__ p, int64_t stride, int ns, int dim, int k,
-                                                       BBox *__restrict__ out) {
+__global__ __launch_bounds__(256) void quantile_kernel(const double *__restrict__ samp, int ns, int k, BBox *__restrict__ out) {
     __shared__ double v[kQuantSamples];
     __shared__ int part[8][kQuantCand][2];
     const int a = blockIdx.x;
-    for (int i = threadIdx.x; i < kQuantSamples; i += 256)
-        v[i] = i < ns ? p[(int64_t)i * stride * dim + a] : __builtin_inf();   // (targets are finite, or the build is refused)
+    for (int i = threadIdx.x; i < kQuantSamples; i += 256) v[i] = samp[a * kQuantSamples + i];   // (+inf beyond ns; targets are finite, or the build is refused)
     __syncthreads();
     const int cl = threadIdx.x & (kQuantCand - 1);
     const int c = blockIdx.y * kQuantCand + cl;
@@ -208,15 +215,15 @@ __global__ __launch_bounds__(256) void quantile_kernel(const double *__restrict_
 // density-weighted mean population of a cell is 1 + N * P(two random points share a cell), and that probability is
 // estimated here at EVERY level at once from the pairs of the sample: with the samples' Morton codes at the finest
 // conceivable level (B bits per axis), two samples share a level-l cell iff their codes agree above dim*l bits, i.e.
-// from level ceil(bitlength(a ^ b) / dim) upwards.  Block (x, y): rows 64x .. 64x+63 against the columns of quarter y,
-// each of its four waves 256 of them; pairs_u[l] += ordered pairs (self-pairs included: the host takes them out) whose
+// from level ceil(bitlength(a ^ b) / dim) upwards.  Block (x, y): rows 64x .. 64x+63 against the columns of sixteenth y,
+// each of its four waves 64 of them (1024 blocks: four waves per SIMD hide the latency of the dependent chain per pair); pairs_u[l] += ordered pairs (self-pairs included: the host takes them out) whose
 // FIRST shared level is l.  (Round 2 sorted the codes and let every sample count at most 32 predecessors: the same
 // numbers wherever a cell holds at most 33 samples, i.e. at every level near the population the host looks for.)
 constexpr int kOccB3 = 9, kOccB2 = 13;
-__global__ __launch_bounds__(256) void occupancy_kernel(const double *__restrict__ p, int64_t stride, int ns, int dim,
-                                                        double clip, BBox *__restrict__ io) {
+__global__ __launch_bounds__(256) void occupancy_kernel(const double *__restrict__ samp, int ns, int dim, double clip,
+                                                        BBox *__restrict__ io) {
     __shared__ uint32_t rowc[64];
-    __shared__ uint32_t colc[kQuantSamples / 4];
+    __shared__ uint32_t colc[kQuantSamples / 16];
     __shared__ unsigned int tot[14];
     const int B = dim == 3 ? kOccB3 : kOccB2;
     double mn[3] = {0, 0, 0}, ext = 0.0;
@@ -237,12 +244,12 @@ __global__ __launch_bounds__(256) void occupancy_kernel(const double *__restrict
     auto code_of = [&](int i) -> uint32_t {
         int cell[3] = {0, 0, 0};
         for (int a = 0; a < dim; ++a) {
-            const double f = (p[(int64_t)i * stride * dim + a] - mn[a]) * inv_h;
+            const double f = (samp[a * kQuantSamples + i] - mn[a]) * inv_h;
             cell[a] = f >= 0.0 ? (f < (double)top ? (int)f : top) : 0;
         }
         return dim == 3 ? (spread3(cell[0]) | (spread3(cell[1]) << 1) | (spread3(cell[2]) << 2)) : (spread2(cell[0]) | (spread2(cell[1]) << 1));
     };
-    constexpr int NC = kQuantSamples / 4;   // columns of a block
+    constexpr int NC = kQuantSamples / 16;   // columns of a block
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * NC;
     if (threadIdx.x < 14) tot[threadIdx.x] = 0u;
     if (threadIdx.x < 64) rowc[threadIdx.x] = r0 + threadIdx.x < ns ? code_of(r0 + threadIdx.x) : 0u;
@@ -254,22 +261,26 @@ __global__ __launch_bounds__(256) void occupancy_kernel(const double *__restrict
     const int jb = wv * (NC / 4);
     int jn = ns - (c0 + jb);               // columns of this wave that are real samples (wave-uniform)
     jn = jn < 0 ? 0 : (jn > NC / 4 ? NC / 4 : jn);
+    // 64 pairs per lane: the 8-bit fields of h0 / h1 (one per first-shared level) cannot overflow
+    unsigned long long h0 = 0ull, h1 = 0ull;
+    auto pair = [&](int j) {
+        const uint32_t x = ci ^ colc[jb + j];   // (every lane reads the same word: a broadcast)
+        const int nb = x ? 32 - __clz((int)x) : 0;
+        const int lmin = dim == 3 ? (nb + 2) / 3 : (nb + 1) >> 1;
+        const unsigned long long one = 1ull << (8 * (lmin & 7));
+        h0 += lmin < 8 ? one : 0ull;
+        h1 += lmin < 8 ? 0ull : one;
+    };
+    static_assert(NC / 4 == 64, "a wave takes 64 columns");
+    if (jn == 64) {
+#pragma unroll 16
+        for (int j = 0; j < 64; ++j) pair(j);
+    } else {
+        for (int j = 0; j < jn; ++j) pair(j);
+    }
     unsigned int cnt[14];
 #pragma unroll
-    for (int l = 0; l < 14; ++l) cnt[l] = 0u;
-    for (int jj = 0; jj < jn; jj += 128) {   // at most 128 pairs per flush: the 8-bit fields cannot overflow
-        unsigned long long h0 = 0ull, h1 = 0ull;
-        const int je = jj + 128 < jn ? jj + 128 : jn;
-        for (int j = jj; j < je; ++j) {
-            const uint32_t x = ci ^ colc[jb + j];   // (every lane reads the same word: a broadcast)
-            const int nb = x ? 32 - __clz((int)x) : 0;
-            const int lmin = dim == 3 ? (nb + 2) / 3 : (nb + 1) >> 1;
-            if (lmin < 8) h0 += 1ull << (8 * lmin);
-            else h1 += 1ull << (8 * (lmin - 8));
-        }
-#pragma unroll
-        for (int l = 0; l < 14; ++l) cnt[l] += (unsigned int)(((l < 8 ? h0 : h1) >> (8 * (l & 7))) & 0xffull);
-    }
+    for (int l = 0; l < 14; ++l) cnt[l] = (unsigned int)(((l < 8 ? h0 : h1) >> (8 * (l & 7))) & 0xffull);
 #pragma unroll
     for (int l = 0; l < 14; ++l) {
         unsigned int v = row_ok ? cnt[l] : 0u;
@@ -318,11 +329,16 @@ __global__ __launch_bounds__(GB) void scan_block_kernel(const uint32_t *__restri
     const int tid = threadIdx.x;
     const int64_t base = ((int64_t)blockIdx.x * GB + tid) * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS], tot = 0;
+    const bool whole = base + SCAN_ITEMS <= len;   // (in / out are 256-byte aligned scratch: two 16-byte accesses per thread)
+    if (whole) {
+        const uint4 a = ((const uint4 *)(in + base))[0], b = ((const uint4 *)(in + base))[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        v[k] = base + k < len ? in[base + k] : 0u;
-        tot += v[k];
+        for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = base + k < len ? in[base + k] : 0u;
     }
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) tot += v[k];
     // inclusive wave scan of tot
     uint32_t inc = tot;
 #pragma unroll
@@ -335,10 +351,21 @@ __global__ __launch_bounds__(GB) void scan_block_kernel(const uint32_t *__restri
     uint32_t woff = 0;
     for (int w = 0; w < (tid >> 6); ++w) woff += wsum[w];
     uint32_t run = woff + inc - tot;
+    if (whole) {
+        uint32_t o[SCAN_ITEMS];
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (base + k < len) out[base + k] = run;
-        run += v[k];
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            o[k] = run;
+            run += v[k];
+        }
+        ((uint4 *)(out + base))[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        ((uint4 *)(out + base))[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            if (base + k < len) out[base + k] = run;
+            run += v[k];
+        }
     }
     if (tid == GB - 1) bsum[blockIdx.x] = woff + inc;
 }
@@ -370,9 +397,16 @@ __global__ __launch_bounds__(GB) void scan_add_kernel(uint32_t *__restrict__ out
                                                      int64_t len, uint32_t total_at_end) {
     const int64_t base = ((int64_t)blockIdx.x * GB + threadIdx.x) * SCAN_ITEMS;
     const uint32_t off = bsum[blockIdx.x];
+    if (base + SCAN_ITEMS <= len) {
+        uint4 a = ((uint4 *)(out + base))[0], b = ((uint4 *)(out + base))[1];
+        a.x += off; a.y += off; a.z += off; a.w += off; b.x += off; b.y += off; b.z += off; b.w += off;
+        ((uint4 *)(out + base))[0] = a;
+        ((uint4 *)(out + base))[1] = b;
+    } else {
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < len) out[base + k] += off;
+        for (int k = 0; k < SCAN_ITEMS; ++k)
+            if (base + k < len) out[base + k] += off;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) out[len] = total_at_end;
 }
 
@@ -1547,16 +1581,13 @@ int grid_build_begin(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBu
     gb.usable = false;
     if (int rc = ensure(ctx, ctx->partials, sizeof(double) * kMaxPartials * kSumSlots)) return rc;
     if (int rc = ensure(ctx, ctx->small, kSmallBytes)) return rc;
-    if (!ctx->pinned) ICP_HIP_CHECK(hipHostMalloc(&ctx->pinned, 1024, hipHostMallocDefault));
-    static_assert(sizeof(BBox) <= 512 && 768 * 8 + sizeof(BBox) <= kSmallBytes && 1024 * 8 * 2 <= kMaxPartials * kSumSlots,
+    if (!ctx->pinned) ICP_HIP_CHECK(hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault));
+    static_assert(sizeof(BBox) <= 2048 && 768 * 8 + sizeof(BBox) <= kSmallBytes && 1024 * 8 * 2 <= kMaxPartials * kSumSlots,
                   "scratch of the two concurrent builds overlaps");
     double *part = (double *)ctx->partials.ptr + (stable ? 1024 * 8 : 0);
     BBox *dbox = (BBox *)((double *)ctx->small.ptr + (stable ? 768 : 512));
     int nb = (int)((m + GB - 1) / GB);
     if (nb > 1024) nb = 1024;
-    if (dim == 3) hipLaunchKernelGGL(bbox_kernel<3>, dim3(nb), dim3(GB), 0, st, tgt, m, part);
-    else hipLaunchKernelGGL(bbox_kernel<2>, dim3(nb), dim3(GB), 0, st, tgt, m, part);
-    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(448), 0, st, (const double *)part, nb, dbox);
     ICP_HIP_CHECK(hipGetLastError());
     // Robust extents.  A uniform grid over the bounding box degenerates when a few points lie far out (one outlier at
     // 1e6 puts a whole unit-size cloud into ONE cell: the search is then a full scan per query) and wastes resolution on
@@ -1567,12 +1598,19 @@ int grid_build_begin(icp_ctx *ctx, const double *tgt, int64_t m, int dim, GridBu
     const double clip = grid_clip();
     const int ns = (int)std::min<int64_t>(kQuantSamples, m);
     const bool robust = clip >= 0.0 && ns >= 64 && !stable;  // (a sorted SOURCE only needs an order: any extents do)
+    // the sample of the statistics kernels, compact and per axis, behind the partial rows of both builds and of the means
+    static_assert(1024 * 8 * 2 + 3 * kQuantSamples <= kMaxPartials * kSumSlots, "no room for the sample");
+    double *samp = robust ? (double *)ctx->partials.ptr + 1024 * 8 * 2 : nullptr;
+    if (samp && nb < kQuantSamples / GB) nb = kQuantSamples / GB;   // (the sample is gathered by the first 16 blocks)
+    if (dim == 3) hipLaunchKernelGGL(bbox_kernel<3>, dim3(nb), dim3(GB), 0, st, tgt, m, part, m / ns, ns, samp);
+    else hipLaunchKernelGGL(bbox_kernel<2>, dim3(nb), dim3(GB), 0, st, tgt, m, part, m / ns, ns, samp);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(448), 0, st, (const double *)part, nb, dbox);
     if (robust)  // (same stream, after bbox_final_kernel: it adds its six numbers to the same record)
-        hipLaunchKernelGGL(quantile_kernel, dim3(dim, kQuantSamples / kQuantCand), dim3(256), 0, st, tgt, m / ns, ns, dim, std::max(1, ns / 100), dbox);
+        hipLaunchKernelGGL(quantile_kernel, dim3(dim, kQuantSamples / kQuantCand), dim3(256), 0, st, (const double *)samp, ns, std::max(1, ns / 100), dbox);
     const bool adaptive = robust && env_bits() <= 0 && grid_occ_target() > 0.0;
-    if (adaptive) hipLaunchKernelGGL(occupancy_kernel, dim3(kQuantSamples / 64, 4), dim3(256), 0, st, tgt, m / ns, ns, dim, clip, dbox);
+    if (adaptive) hipLaunchKernelGGL(occupancy_kernel, dim3(kQuantSamples / 64, 16), dim3(256), 0, st, (const double *)samp, ns, dim, clip, dbox);
     ICP_HIP_CHECK(hipGetLastError());
-    void *host = (char *)ctx->pinned + (stable ? 512 : 0);
+    void *host = (char *)ctx->pinned + (stable ? 2048 : 0);
     ICP_HIP_CHECK(hipMemcpyAsync(host, dbox, sizeof(BBox), hipMemcpyDeviceToHost, st));
     hipEvent_t &ev = ctx->stat_ev[stable ? 1 : 0];
     if (!ev) ICP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
