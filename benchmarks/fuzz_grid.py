@@ -55,13 +55,40 @@ def main():
     ap.add_argument("--max-n", type=int, default=200000)
     ap.add_argument("--loop", action="store_true", help="fuzz the fused ICP loop (icp_rigid_run: grid, sorted source, positions, "
                                                        "hints) against the same loop on the full scan instead")
+    ap.add_argument("--coherent", action="store_true", help="fuzz the coherent loop (ICP_COHERENT: rows whose match is provably "
+                                                           "unchanged skip the search) against the plain fused loop: T, "
+                                                           "correspondences and errors bit for bit, ties and duplicates included")
     args = ap.parse_args()
     import torch
     from icp_amd import rigid, nicp
     rng = np.random.default_rng(args.seed)
     bad = 0
     t0 = time.perf_counter()
-    for case in range(args.cases if args.loop else 0):
+    for case in range(args.cases if args.coherent else 0):
+        dim = int(rng.choice([2, 3]))
+        m = int(np.exp(rng.uniform(np.log(8), np.log(args.max_n))))
+        n = int(np.exp(rng.uniform(np.log(8), np.log(args.max_n))))
+        kt = str(rng.choice(KINDS))
+        tgt = cloud(rng, m, dim, kt)
+        a = rng.uniform(-0.2, 0.2)
+        R = np.eye(dim)
+        R[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        src = (tgt[rng.integers(0, m, n)] + rng.standard_normal((n, dim)) * rng.choice([0.0, 1e-3, 0.05])) @ R.T + rng.uniform(-0.1, 0.1, dim)
+        if rng.integers(0, 6) == 0:
+            src[rng.integers(0, n, max(1, n // 50))] = rng.choice([np.nan, np.inf, 1e9])   # rows no bound can hold
+        run = int(rng.integers(2, 41))
+        tol = float(rng.choice([0.0, 1e-6, 1e-3]))
+        use_tol = bool(rng.integers(0, 2))
+        A = rigid.rigid_icp(src, tgt, tol, run, use_tol=use_tol, force_grid=True, want_idx=True)
+        B = rigid.rigid_icp(src, tgt, tol, run, use_tol=use_tol, force_grid=True, want_idx=True, coherent=True)
+        k = int(A["iters"].cpu()[0])
+        bits = lambda t: t.contiguous().view(torch.int64)   # (NaN rows make T and the errors NaN: compare the bit patterns)
+        same = (k == int(B["iters"].cpu()[0]) and torch.equal(bits(A["T"]), bits(B["T"])) and torch.equal(A["idx"], B["idx"])
+                and torch.equal(bits(A["err_hist"][:k]), bits(B["err_hist"][:k])))
+        bad += 0 if same else 1
+        print("%4d %-5s coherent dim %d n %7d m %7d tgt %-8s run %2d (%2d done) tol %g/%d  idx_diff %d" %
+              (case, "ok" if same else "FAIL", dim, n, m, kt, run, k, tol, use_tol, int((A["idx"] != B["idx"]).sum())), flush=True)
+    for case in range(args.cases if (args.loop and not args.coherent) else 0):
         # tie-free distributions only: the two loops sum in different orders, so their transforms differ in the last
         # bits, and an exact tie may then legitimately resolve differently
         dim = int(rng.choice([2, 3]))
@@ -93,7 +120,7 @@ def main():
         bad += 0 if ok else 1
         print("%4d %-5s loop dim %d n %7d m %7d tgt %-8s run %d sqrt %d  idx_diff_vs_scan %d reproducible %d" %
               (case, "ok" if ok else "FAIL", dim, n, m, kt, run, sq, nidx, same), flush=True)
-    for case in range(0 if args.loop else args.cases):
+    for case in range(0 if (args.loop or args.coherent) else args.cases):
         dim = int(rng.choice([2, 3]))
         n = int(np.exp(rng.uniform(0, np.log(args.max_n))))
         m = int(np.exp(rng.uniform(0, np.log(args.max_n))))

@@ -19,6 +19,7 @@ ICP_FORCE_BRUTE = 2
 ICP_FORCE_GRID = 4
 ICP_HINT_IDX = 8
 ICP_NO_FUSE = 16
+ICP_COHERENT = 32
 
 c_dp = ctypes.c_void_p
 c_i64 = ctypes.c_int64

@@ -344,7 +344,7 @@ bool grid_worthwhile(int64_t n, int64_t m, unsigned flags) {
 // prebuilt grid over tgt; without it one is built here when that is worthwhile.
 int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
                      unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done,
-                     const GridBuild *grid, const int32_t *hint_from, const FusedApply *fa) {
+                     const GridBuild *grid, const int32_t *hint_from, const FusedApply *fa, const Coherence *coh) {
     GridBuild local;
     if (!grid && grid_worthwhile(n, m, flags)) {
         if (int rc = grid_build(ctx, tgt, m, dim, local)) return rc;
@@ -358,7 +358,7 @@ int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *t
     }
     auto argmin = [&](double *d2) -> int {
         if (use_grid) return grid_query(ctx, *grid, src, n, nullptr, false, nullptr, idx_out, d2, done,
-                                        (flags & ICP_HINT_IDX) ? (hint_from ? hint_from : idx_out) : nullptr, pos_mode, fa);
+                                        (flags & ICP_HINT_IDX) ? (hint_from ? hint_from : idx_out) : nullptr, pos_mode, fa, coh);
         return dim == 3 ? launch_closest<3, false>(ctx, src, n, tgt, m, nullptr, idx_out, d2, done)
                         : launch_closest<2, false>(ctx, src, n, tgt, m, nullptr, idx_out, d2, done);
     };

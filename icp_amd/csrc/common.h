@@ -58,6 +58,7 @@ struct icp_ctx {
     icp::Scratch sort_tmp, sort_tmp_tgt;
     icp::Scratch defer;                                   // grid search: queries handed to the wave-per-query pass
     icp::Scratch err_part;                                // fused rigid loop: per-block error sums of a search
+    icp::Scratch coh;                                     // coherent rigid loop: per-query bound + reference position
     void *defer_cleared = nullptr;                        // buffer whose two counters are known to be in step
     int defer_parity = 0;                                 // which of the two counters the next search uses
     // nicp_solve replays its CG iterations as a hipGraph; graphs cannot be captured on the legacy
@@ -123,9 +124,17 @@ struct FusedApply {
     double **err_part;
     int *n_err;
 };
+// Coherent rigid loop (grid.hip, grid_query_kernel<BND>): per query, a lower bound on the computed d2 to every target other
+// than the one returned, and the position it was taken at.  A search given these writes them; a FUSED search given them
+// first tries to prove every hinted record still nearest and searches only for the queries where it cannot.
+struct Coherence {
+    double *lb2;      // [n]
+    double *sref;     // [n, dim]
+    uint32_t *count;  // [blocks of the test pass] queries of each block that could not be proven unchanged this iteration
+};
 int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
                const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done, const int32_t *hint = nullptr,
-               bool pos_mode = false, const FusedApply *fa = nullptr);
+               bool pos_mode = false, const FusedApply *fa = nullptr, const Coherence *coh = nullptr);
 // internal flag of closest_dispatch: correspondences (and hints) are SORTED POSITIONS into GridBuild::spts /
 // sidx instead of original indices (icp_rigid_run keeps them that way between iterations: the gathers of the
 // reduction kernels then walk the Morton-sorted copy almost sequentially)
@@ -134,7 +143,8 @@ constexpr unsigned ICP_INTERNAL_POS = 0x10000u;
 // correspondence buffers)
 int closest_dispatch(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
                      unsigned flags, int32_t *idx_out, double *d2_out, const int32_t *done,
-                     const GridBuild *grid = nullptr, const int32_t *hint_from = nullptr, const FusedApply *fa = nullptr);
+                     const GridBuild *grid = nullptr, const int32_t *hint_from = nullptr, const FusedApply *fa = nullptr,
+                     const Coherence *coh = nullptr);
 bool grid_worthwhile(int64_t n, int64_t m, unsigned flags);
 bool grid_fusable();  // false under the single-pass switches of the grid search: rigid loops then take the unfused form
 // exact k nearest (k = 6 or 8) by the key fl(sqrt(d2)), ties to the lower index, through a built grid

@@ -68,7 +68,7 @@ extern "C" int icp_ctx_destroy(icp_ctx *ctx) {
     icp::Scratch *all[] = {&ctx->split_d2, &ctx->split_idx, &ctx->partials, &ctx->small,  &ctx->work_a,
                            &ctx->work_b,   &ctx->work_c,    &ctx->work_d,   &ctx->grid_a, &ctx->grid_b,
                            &ctx->grid_c,   &ctx->grid_d,    &ctx->grid_e,   &ctx->sort_a, &ctx->sort_b,
-                           &ctx->sort_c,   &ctx->sort_d,    &ctx->defer,    &ctx->sort_tmp, &ctx->err_part, &ctx->sort_tmp_tgt};
+                           &ctx->sort_c,   &ctx->sort_d,    &ctx->defer,    &ctx->sort_tmp, &ctx->err_part, &ctx->sort_tmp_tgt, &ctx->coh};
     for (icp::Scratch *s : all)
         if (s->ptr) (void)hipFree(s->ptr);
     if (ctx->side) {

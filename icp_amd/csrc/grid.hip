@@ -486,6 +486,11 @@ __device__ __forceinline__ bool better2(double da, int32_t ia, double db, int32_
     return da < db || (da == db && ia < ib);
 }
 
+#ifndef ICP_COH_G
+#define ICP_COH_G 8
+#endif
+constexpr int kCohG = ICP_COH_G;   // lanes per query in the deferred pass of a coherent iteration (32 / 16 / 8: 60 / 51 / 47 us)
+
 // LE = false: argmin (d2, index).  LE = true: lowest index with d2 <= thr[q].
 // A query the per-lane pass gave up on after `cap` levels: state to resume from
 struct Deferred {
@@ -493,13 +498,30 @@ struct Deferred {
     uint32_t bp;  // sorted position of the best record so far
     double best;
     double s[3];  // the query as the per-lane pass searched it (moved, in the fused loop): saves the second pass a dependent load
+    double second;  // BND searches: least d2 among the OTHER records evaluated so far
 };
 
 // FUSED (the rigid loop from its second iteration on, kabsch.hip): the query is src[q] moved by the transform the last
 // solve left in device memory (the arithmetic of apply_err_kernel, so the same bits as a materialised copy), and the
 // distance to its hint -- last iteration's correspondence -- is that iteration's error term (icp_3d.py:113-114):
 // the block's sum of them goes to err_part[block], which saves the loop a streaming kernel and a reduction launch.
-template <int DIM, bool LE, int QB, int WPE, bool FUSED = false, int LISTN = 4, int UNRN = 3>
+//
+// BND (the coherent rigid loop, kabsch.hip): a TWO-nearest search.  Cells are pruned and the search is
+// stopped against the second-best d2 instead of the best (the returned argmin is the same: less is pruned), so that
+// `second` ends as the least computed d2 over ALL targets other than the one returned -- every target is evaluated, or
+// lies in a cell pruned on bound > second, or beyond a box left on second < gap^2 -- and it is stored per query (lb2)
+// together with the query's position (sref).
+// COH = 1 (FUSED && BND; the test pass of a coherent iteration): form the moved query and the error term as FUSED does,
+// then try to PROVE the hinted record still nearest: with delta = |s - sref|, every other target is at least
+// sqrt(lb2) - delta away (triangle inequality, with slack for every rounding involved), so if the hinted record is nearer
+// than that no other target's computed d2 can reach, let alone tie, its own: the full scan would return the same index.
+// Such a query keeps its record; the others go straight to the deferred pass (one half-wave per query: a few thousand
+// scattered queries are a latency problem -- run through the per-lane kernel they took 70 us, the longest lane of the few
+// resident waves), as Deferred records seeded with the hinted record and with an upper bound on the new second-best d2
+// (the two targets nearest at sref are both within sqrt(lb2) + delta now).  Block b compacts its records into ITS OWN
+// region of the list (QB slots) and writes their number to coh_count[b]: no atomics (16 000 per-wave atomics on one
+// counter took 170 us, 4 096 per-block ones on sixteen counters still 40 us of a 57 us pass: now 17 us).
+template <int DIM, bool LE, int QB, int WPE, bool FUSED = false, int LISTN = 4, int UNRN = 3, bool BND = false, int COH = 0>
 __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void grid_query_kernel(const double *__restrict__ src, int64_t n,
                                                        const int32_t *__restrict__ qorder,
                                                        const double4 *__restrict__ recs,
@@ -511,7 +533,11 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                                                        const int32_t *hint, const uint32_t *__restrict__ inv, uint32_t m,
                                                        int pos_mode, int xcd_chunk, const double *__restrict__ Rm = nullptr,
                                                        const double *__restrict__ tv = nullptr,
-                                                       double *__restrict__ err_part = nullptr) {
+                                                       double *__restrict__ err_part = nullptr,
+                                                       double *__restrict__ lb2_io = nullptr, double *__restrict__ sref_io = nullptr,
+                                                       uint32_t *__restrict__ coh_count = nullptr) {
+    static_assert(!BND || !LE, "bounds belong to the argmin search");
+    static_assert(COH == 0 || (BND && FUSED), "the coherent passes are forms of the fused, bounded search");
     if (done && *done) return;
     // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), each
     // with its own 4 MiB L2, and the queries arrive in Morton order.  The launch is cut into super-chunks of
@@ -568,8 +594,19 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             // error term of the previous iteration: ||nn - ss|| with nn the hinted record (d2 summed as apply_err_kernel
             // sums it: ((0 + dx^2) + dy^2) + dz^2); a non-finite query contributes its NaN / inf like there
             double e = 0.0;
+            double hd2 = 0.0;        // COH: the computed d2 to the hinted record (eval()'s arithmetic), whether the bound
+            bool keep = false;       // taken at the last search still proves it the nearest, and, where it does not, an
+            double sec0 = __builtin_inf();   // upper bound on the second-best d2 the search will find
+            int32_t hid = 0x7fffffff;
+            uint32_t hpos = 0;
             if (in_range) {
                 const uint32_t h = (uint32_t)hint[q];
+                double lb2 = 0.0, sr[DIM];
+                if (COH == 1) {      // (issued with the record's load)
+                    lb2 = lb2_io[q];
+#pragma unroll
+                    for (int a = 0; a < DIM; ++a) sr[a] = sref_io[q * DIM + a];
+                }
                 const double4 rc = recs[h < m ? h : 0u];   // (always in range inside the loop; never fault on a bad one)
                 const double dx = rc.x - s[0], dy = rc.y - s[1];
                 double d = dx * dx + dy * dy;
@@ -578,6 +615,30 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     d = d + dz * dz;
                 }
                 e = sqrt(d);
+                if (COH == 1) {
+                    // every other target t had computed d2(s_ref, t) >= lb2, so its true distance from s_ref is at least
+                    // sqrt(lb2) (1 - 3e-16), from s at least that minus |s - s_ref|, and its computed d2 from s at least the
+                    // square of that times (1 - 6e-16): a relative slack of 1e-12 on each factor covers all of it
+                    // (and 1e-280 keeps every quantity far above the underflow range, where those relative errors hold)
+                    hd2 = d;
+                    double m2 = 0.0;
+#pragma unroll
+                    for (int a = 0; a < DIM; ++a) m2 += (s[a] - sr[a]) * (s[a] - sr[a]);
+                    const double rl = __dsqrt_rn(lb2), dl = __dsqrt_rn(m2);
+                    const double L = rl * (1.0 - 1e-12) - dl * (1.0 + 1e-12);
+                    keep = h < m && L > 0.0 && lb2 > 1e-280 && L * L * (1.0 - 1e-12) > d && L * L > 1e-280;
+                    // the two targets nearest at sref lie within rl (1 + 3e-16) of it, hence within that + |s - sref| of s:
+                    // the search will find a second-best d2 no larger than this (NaN / inf: nothing is pruned on it)
+                    const double U = (rl + dl) * (1.0 + 1e-12);
+                    sec0 = U * U * (1.0 + 1e-12);
+                    if (h < m) {
+                        hid = (int32_t)__double_as_longlong(rc.w);
+                        hpos = h;
+                    } else {
+                        hd2 = __builtin_inf();
+                        sec0 = __builtin_inf();
+                    }
+                }
             }
             __shared__ double ered[QB / 64];
             const double w = wave_sum(e);
@@ -589,9 +650,51 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 for (int k = 1; k < QB / 64; ++k) v += ered[k];
                 err_part[blk] = v;
             }
+            if (COH == 1) {
+                bool finite = true;
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) finite = finite && fabs(s[a]) < __builtin_inf();
+                if (in_range && !finite) {   // (np.argmin of a constant NaN / inf row: index 0; never kept)
+                    idx_out[q] = (int32_t)inv[0];
+                    lb2_io[q] = 0.0;
+                }
+                if (in_range && finite && keep) idx_out[q] = hint[q];   // fused loop: hints and results are sorted positions
+                // the others: compacted over the block into the block's own region of the list
+                const bool go = in_range && finite && !keep;
+                __shared__ uint32_t wcnt[QB / 64];
+                const unsigned long long gm = __builtin_amdgcn_ballot_w64(go);
+                const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+                if (ln == 0) wcnt[wv] = (uint32_t)__builtin_popcountll(gm);
+                __syncthreads();
+                uint32_t off = (uint32_t)__builtin_popcountll(gm & ((1ull << ln) - 1ull)), tot = 0;
+#pragma unroll
+                for (int k = 0; k < QB / 64; ++k) {
+                    off += k < wv ? wcnt[k] : 0u;
+                    tot += wcnt[k];
+                }
+                if (threadIdx.x == 0) coh_count[blk] = tot;
+                if (go) {
+                    Deferred dq;
+                    dq.q = (int32_t)q;
+                    dq.level = 0;
+                    dq.bi = hid;
+                    dq.bp = hpos;
+                    dq.best = hd2;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) dq.s[a] = a < DIM ? s[a] : 0.0;
+                    dq.second = sec0;
+                    deferred[(size_t)blk * QB + off] = dq;
+                }
+                return;
+            }
             if (!in_range) return;
+            (void)hd2;
+            (void)sec0;
+            (void)hid;
+            (void)hpos;
         }
         if (!finite) {
+            if (BND) lb2_io[q] = 0.0;   // never kept
             idx_out[q] = pos_mode ? (int32_t)inv[0] : 0;
             if (d2_out) d2_out[q] = LE ? __builtin_inf() : (isnan ? __builtin_nan("") : __builtin_inf());
             return;
@@ -610,6 +713,9 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const int lane_slot = threadIdx.x;
 
     uint32_t bp = 0;  // sorted position of the best record (what pos_mode returns instead of its index)
+    double second = __builtin_inf();   // BND: least d2 among the evaluated records other than the best one
+    // what a cell's bound / the gap is tested against: the best d2, or (BND) the second best
+#define ICP_PRUNE_AT (BND ? second : best)
     auto eval = [&](const double4 &rc, uint32_t pos) {
         const double dx = rc.x - s[0], dy = rc.y - s[1];
         double d = dx * dx + dy * dy;
@@ -618,6 +724,10 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             d = d + dz * dz;
         }
         const int32_t id = (int32_t)__double_as_longlong(rc.w);
+        if (BND) {   // (a record may be met more than once: as the hint, past the end of a range, again one level up)
+            const bool better = d < best || (d == best && id < bi);
+            second = better ? best : ((id != bi && d < second) ? d : second);
+        }
         if (LE) {
             if (d <= thr && id < bi) {
                 bi = id;
@@ -666,6 +776,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             dq.best = best;
 #pragma unroll
             for (int a = 0; a < 3; ++a) dq.s[a] = a < DIM ? s[a] : 0.0;
+            dq.second = second;
             deferred[slot] = dq;
             return;
         }
@@ -715,7 +826,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 inside = inside && okc[2][oz];
                 bound = bound + g2[2][oz];
             }
-            if (inside && !(LE ? (bound > thr) : (bound > best))) mask |= 1u << nb;
+            if (inside && !(LE ? (bound > thr) : (bound > ICP_PRUNE_AT))) mask |= 1u << nb;
         }
         // phase C: fetch the ranges of up to LIST surviving cells in one batch, then every lane walks
         // its own concatenated list.  Cells are taken nearest class first (faces, edges, corners) and
@@ -748,7 +859,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     code |= (oz == 0 ? sp[2][0] : (oz == 1 ? sp[2][1] : sp[2][2]));
                     bound = bound + (oz == 0 ? g2[2][0] : (oz == 1 ? g2[2][1] : g2[2][2]));
                 }
-                if (!LE) have = have && !(bound > best);  // best may have improved since the mask was built
+                if (!LE) have = have && !(bound > ICP_PRUNE_AT);  // best may have improved since the mask was built
                 code = have ? code : 0u;  // exhausted mask: columns -1 may be outside the grid
                 r0[k] = start[(uint64_t)code << (DIM * l)];
                 r1[k] = have ? start[((uint64_t)code + 1) << (DIM * l)] : r0[k];
@@ -767,7 +878,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     const uint2 r = wl[cur][lane_slot];
                     const float f = wlb[cur][lane_slot];
                     ++cur;
-                    if (!LE && (double)f > best) continue;  // a tie (bound == best) is still visited
+                    if (!LE && (double)f > ICP_PRUNE_AT) continue;  // a tie (bound == best) is still visited
                     p = r.x;
                     pe = r.y;
                 }
@@ -805,8 +916,14 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         if (mgap == __builtin_inf()) break;  // box covers the grid
         if (mgap > 0.0) {
             const double m2 = mgap * mgap;
-            if (LE ? (thr < m2) : (best < m2)) break;
+            if (LE ? (thr < m2) : (ICP_PRUNE_AT < m2)) break;
         }
+    }
+#undef ICP_PRUNE_AT
+    if (BND) {
+        lb2_io[q] = second;
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) sref_io[q * DIM + a] = s[a];
     }
     if (dbg) {
         const long long dt = (long long)__builtin_amdgcn_s_memtime() - t_begin;
@@ -853,7 +970,7 @@ __device__ __forceinline__ void unpack_cell(uint32_t v, int *x, int &lvl) {
 constexpr int kSplit = 32;    // a cell above the finest level with more records than this is replaced by its children
 constexpr int kStack = 384;   // cells per group's stack (a cell whose children would not fit is scanned whole)
 
-template <int DIM, bool LE>
+template <int DIM, bool LE, bool BND = false, int GG = ICP_DEFER_G>
 __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restrict__ recs,
                                                         const uint32_t *__restrict__ start, GridParams gp,
                                                         const double *__restrict__ thr_in, int32_t *__restrict__ idx_out,
@@ -861,20 +978,27 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
                                                         const Deferred *__restrict__ deferred,
                                                         const uint32_t *__restrict__ n_deferred,
                                                         uint32_t *__restrict__ next_counter,
-                                                        const uint32_t *__restrict__ inv, int pos_mode, int jump, int split_min) {
+                                                        const uint32_t *__restrict__ inv, int pos_mode, int jump, int split_min,
+                                                        double *__restrict__ lb2_io = nullptr, double *__restrict__ sref_io = nullptr,
+                                                        int nsub = 1, uint32_t sub_cap = 0) {
     // the two counters alternate between searches: nobody touches the other one during this search, so it is
     // cleared here for the next search (before the `done` test, so that it is clear whatever that says)
     if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0u;
     if (done && *done) return;
     constexpr int NBR = DIM == 3 ? 27 : 9;
-    constexpr int G = ICP_DEFER_G;  // lanes per query
+    constexpr int G = GG;  // lanes per query
     constexpr uint32_t GMASK = G == 32 ? 0xffffffffu : ((1u << G) - 1u);
     __shared__ uint32_t stk[64 / G][kStack];
     const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
-    const uint32_t nd = *n_deferred;
-    const uint32_t ngroups = gridDim.x * (64 / G);
-    for (uint32_t it = blockIdx.x * (64 / G) + grp; it < nd; it += ngroups) {
-        const Deferred dq = deferred[it];
+    // nsub = 1: the one list, its length in n_deferred[0].  Coherent iterations: nsub lists of sub_cap slots (one per block
+    // of the test pass), their lengths in n_deferred[0 .. nsub); list y is served by `gps` consecutive groups in turn
+    const uint32_t NG = gridDim.x * (64 / G), gid = blockIdx.x * (64 / G) + grp;
+    const uint32_t gps = NG >= (uint32_t)nsub ? NG / (uint32_t)nsub : 1u;
+    for (uint32_t sub = gid / gps; sub < (uint32_t)nsub; sub += NG / gps) {
+    const uint32_t nd = n_deferred[sub];
+    const Deferred *__restrict__ dsub = deferred + (size_t)sub * sub_cap;
+    for (uint32_t it = gid % gps; it < nd; it += gps) {
+        const Deferred dq = dsub[it];
         const int64_t q = dq.q;
         double s[DIM];
 #pragma unroll
@@ -884,9 +1008,12 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
         double best = dq.best;     // group-uniform between levels
         int32_t bi = dq.bi;
         uint32_t bp = dq.bp;
+        // BND (see grid_query_kernel): `sec` = least d2 among the evaluated records other than the best one, group-uniform
+        // between rounds, and what cells and gaps are tested against instead of `best`
+        double sec = BND ? dq.second : 0.0;
         const double thr = LE ? thr_in[q] : 0.0;
         int l0 = dq.level;
-        if (!LE && jump && best < __builtin_inf()) {
+        if (!LE && jump && (BND ? sec : best) < __builtin_inf()) {
             // The bound the query arrives with (its hint: last iteration's match) already says how far the search has
             // to reach: the first level whose 3^DIM box passes the gap test with it.  The best distance only shrinks,
             // so that level's scan is the last one, and the levels below it -- subsets of its box -- add nothing:
@@ -910,7 +1037,7 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
                     }
                 }
                 if (mgap == __builtin_inf()) break;                 // the box covers the grid
-                if (mgap > 0.0 && best < mgap * mgap) break;        // the same test as at the end of a level below
+                if (mgap > 0.0 && (BND ? sec : best) < mgap * mgap) break;        // the same test as at the end of a level below
             }
         }
         for (int l = l0; l <= gp.bits; ++l) {
@@ -968,7 +1095,7 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
                         g = g > 0.0 ? g : 0.0;
                         bound = bound + g * g;   // same association as the per-lane pass: ((gx + gy) + gz)
                     }
-                    if (!(LE ? (bound > thr) : (bound > best))) {
+                    if (!(LE ? (bound > thr) : (bound > (BND ? sec : best)))) {
                         const uint32_t code = morton<DIM>(x);
                         r0 = start[(uint64_t)code << (DIM * lvl)];
                         r1 = start[((uint64_t)code + 1) << (DIM * lvl)];
@@ -1009,6 +1136,7 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
                 double lb = best;
                 int32_t li = bi;
                 uint32_t lp = bp;
+                double ls = sec;   // BND: this lane's second best
                 for (uint32_t base = 0; base < total; base += G) {      // group-uniform trip count: the shuffles need every lane
                     const uint32_t tpos = base + lane;
                     int c = 0;  // last lane with excl[c] <= tpos
@@ -1028,6 +1156,10 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
                             d = d + dz * dz;
                         }
                         const int32_t id = (int32_t)__double_as_longlong(rc.w);
+                        if (BND) {
+                            const bool better = d < lb || (d == lb && id < li);
+                            ls = better ? lb : ((id != li && d < ls) ? d : ls);
+                        }
                         if (LE) {
                             if (d <= thr && id < li) {
                                 li = id;
@@ -1042,6 +1174,8 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
                     }
                 }
                 if (total > 0) {
+                    const double lb_own = lb;
+                    const int32_t li_own = li;
                     // group argmin of (d2, index); the position rides along
 #pragma unroll
                     for (int o = G / 2; o > 0; o >>= 1) {
@@ -1057,6 +1191,17 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
                     best = lb;
                     bi = li;
                     bp = lp;
+                    if (BND) {
+                        // the group's second best: a lane whose own best is not the group's contributes that best (its
+                        // own second is no smaller), the others their second
+                        double c = li_own == li ? ls : lb_own;
+#pragma unroll
+                        for (int o = G / 2; o > 0; o >>= 1) {
+                            const double oc = shfl_xor_f64(c, o);
+                            c = oc < c ? oc : c;
+                        }
+                        sec = c;
+                    }
                 }
             }
             if (ncl == 1) break;
@@ -1076,7 +1221,7 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
             if (mgap == __builtin_inf()) break;
             if (mgap > 0.0) {
                 const double m2 = mgap * mgap;
-                if (LE ? (thr < m2) : (best < m2)) break;
+                if (LE ? (thr < m2) : ((BND ? sec : best) < m2)) break;
             }
         }
         if (lane == 0) {
@@ -1086,7 +1231,13 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
             }
             idx_out[q] = pos_mode ? (int32_t)bp : bi;
             if (d2_out) d2_out[q] = best;
+            if (BND) {
+                lb2_io[q] = sec;
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) sref_io[q * DIM + a] = s[a];
+            }
         }
+    }
     }
 }
 
@@ -1788,11 +1939,17 @@ bool grid_fusable() { return grid_cap() < 1000; }
 
 int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
                const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done, const int32_t *hint, bool pos_mode,
-               const FusedApply *fa) {
+               const FusedApply *fa, const Coherence *coh) {
     hipStream_t st = ctx->stream;
     const int cap = grid_cap();
+    if (coh && (le || qorder || d2_out || thr || cap >= 1000 || !pos_mode)) {
+        set_error("grid_query: bounds come with the two-pass argmin search over sorted positions");
+        return ICP_ERR_ARG;
+    }
+    double *clb = coh ? coh->lb2 : nullptr, *csr = coh ? coh->sref : nullptr;
     const size_t defer_cap = ctx->defer.cap;
-    if (int rc = ensure(ctx, ctx->defer, (size_t)n * sizeof(Deferred) + 256)) return rc;
+    // (coherent iterations: one region of 256 records per block of the test pass, padded block count)
+    if (int rc = ensure(ctx, ctx->defer, ((size_t)n + (coh ? (size_t)16 * 256 : 0)) * sizeof(Deferred) + 256)) return rc;
     if (ctx->defer.cap != defer_cap) ctx->defer_cleared = nullptr;   // reallocated (possibly at the same address)
     // two counters in the header, used alternately: the deferred pass of one search clears the counter of the
     // next, which saves a 4 us memset launch per search (1 % of an iteration at 2^20 points)
@@ -1837,19 +1994,42 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
         *fa->err_part = (double *)ctx->err_part.ptr;
         *fa->n_err = (int)nb;
     }
-#define ICP_GQ2(D, L, F, LN, UN) \
+#define ICP_GQ3(D, L, F, LN, UN, B) \
     do { \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[0], st); \
-        hipLaunchKernelGGL((grid_query_kernel<D, L, 256, 4, F, LN, UN>), dim3(nb), dim3(256), 0, st, src, n, qorder, (const double4 *)gb.recs, \
+        hipLaunchKernelGGL((grid_query_kernel<D, L, 256, 4, F, LN, UN, B>), dim3(nb), dim3(256), 0, st, src, n, qorder, (const double4 *)gb.recs, \
                            (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, g_grid_dbg, cap, dlist, ndef, hint, \
                            (const uint32_t *)gb.inv, (uint32_t)gb.m, pos_mode ? 1 : 0, xcd_chunk, fR, ft, \
-                           fa ? (double *)ctx->err_part.ptr : (double *)nullptr); \
+                           fa ? (double *)ctx->err_part.ptr : (double *)nullptr, clb, csr); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[1], st); \
         if (cap < 1000) \
-            hipLaunchKernelGGL((grid_defer_kernel<D, L>), dim3(nb2), dim3(64), 0, st, (const double4 *)gb.recs, \
+            hipLaunchKernelGGL((grid_defer_kernel<D, L, B>), dim3(nb2), dim3(64), 0, st, (const double4 *)gb.recs, \
                                (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (const Deferred *)dlist, \
                                (const uint32_t *)ndef, ndef_next, (const uint32_t *)gb.inv, pos_mode ? 1 : 0, \
-                               jump_env >= 0 ? jump_env : ((hint && pos_mode) ? 1 : 0), split_env); \
+                               jump_env >= 0 ? jump_env : ((hint && pos_mode) ? 1 : 0), split_env, clb, csr); \
+        if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
+    } while (0)
+#define ICP_GQ2(D, L, F, LN, UN) ICP_GQ3(D, L, F, LN, UN, false)
+    // a coherent iteration: test pass over all queries (error sum; proof, or a record for the deferred pass) -> deferred pass
+#define ICP_GQC(D) \
+    do { \
+        if (g_grid_events) (void)hipEventRecord(g_grid_events[0], st); \
+        hipLaunchKernelGGL((grid_query_kernel<D, false, 256, 8, true, 4, 3, true, 1>), dim3(nb), dim3(256), 0, st, src, n, qorder, (const double4 *)gb.recs, \
+                           (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (long long *)nullptr, cap, dlist, ndef, hint, \
+                           (const uint32_t *)gb.inv, (uint32_t)gb.m, 1, xcd_chunk, fR, ft, (double *)ctx->err_part.ptr, clb, csr, coh->count); \
+        if (coh_trace) { \
+            std::vector<uint32_t> hc(nb); \
+            uint32_t tot = 0; \
+            (void)hipMemcpyAsync(hc.data(), coh->count, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st); \
+            (void)hipStreamSynchronize(st); \
+            for (unsigned y = 0; y < nb; ++y) tot += hc[y]; \
+            std::fprintf(stderr, "coherent iteration: %u of %lld queries searched\n", tot, (long long)n); \
+        } \
+        if (g_grid_events) (void)hipEventRecord(g_grid_events[1], st); \
+        hipLaunchKernelGGL((grid_defer_kernel<D, false, true, kCohG>), dim3(coh_blocks), dim3(64), 0, st, (const double4 *)gb.recs, \
+                           (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (const Deferred *)dlist, \
+                           (const uint32_t *)coh->count, ndef_next, (const uint32_t *)gb.inv, 1, \
+                           jump_env >= 0 ? jump_env : 1, split_env, clb, csr, (int)nb, 256u); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
     } while (0)
     static const int list8 = getenv("ICP_GRID_LIST8") ? atoi(getenv("ICP_GRID_LIST8")) : 0;
@@ -1862,7 +2042,15 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
         if (list8) ICP_GQ2(D, L, F, 8, 4); \
         else ICP_GQ2(D, L, F, 4, 3); \
     } while (0)
-    if (gb.gp.dim == 3) {
+    static const bool coh_trace = getenv("ICP_COHERENT_TRACE") != nullptr;
+    static const unsigned coh_blocks = getenv("ICP_COHERENT_BLOCKS") ? (unsigned)atoi(getenv("ICP_COHERENT_BLOCKS")) : 8192u;
+    if (coh && fa) {
+        if (gb.gp.dim == 3) ICP_GQC(3);
+        else ICP_GQC(2);
+    } else if (coh) {   // first iteration: the bounded search for every query (the list-of-8 probe has no bounded variant)
+        if (gb.gp.dim == 3) ICP_GQ3(3, false, false, 4, 3, true);
+        else ICP_GQ3(2, false, false, 4, 3, true);
+    } else if (gb.gp.dim == 3) {
         if (le) ICP_GQL(3, true, false);
         else if (fa) ICP_GQL(3, false, true);
         else ICP_GQL(3, false, false);
@@ -1873,6 +2061,8 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
     }
 #undef ICP_GQL
 #undef ICP_GQ2
+#undef ICP_GQ3
+#undef ICP_GQC
     ICP_HIP_CHECK(hipGetLastError());
     return ICP_OK;
 }

@@ -986,7 +986,18 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
     if (ss) ICP_HIP_CHECK(hipMemcpyAsync(ss, src, (size_t)n * dim * sizeof(double), hipMemcpyDeviceToDevice, s));  // icp_3d.py:104
     const int32_t *done = &st->done;
     const double *tgt_rows = pos ? grid.spts : tgt;
-    flags = (flags & ~(unsigned)(ICP_HINT_IDX | ICP_NO_FUSE)) | (pos ? ICP_INTERNAL_POS : 0u);
+    // coherent loop (ICP_COHERENT, icp_hip.h; grid_query_kernel<BND>): per source row a bound and the position it was taken at
+    static const int coh_env = getenv("ICP_COHERENT") ? atoi(getenv("ICP_COHERENT")) : -1;
+    const bool coherent = fused && (coh_env >= 0 ? coh_env != 0 : (flags & ICP_COHERENT) != 0);
+    Coherence coh = {nullptr, nullptr, nullptr};
+    if (coherent) {
+        const size_t cnt_bytes = (((size_t)(n + 255) / 256 + 16) * sizeof(uint32_t) + 255) & ~(size_t)255;   // (padded block count)
+        if (int rc = ensure(ctx, ctx->coh, cnt_bytes + (size_t)n * (dim + 1) * sizeof(double))) return rc;
+        coh.count = (uint32_t *)ctx->coh.ptr;
+        coh.lb2 = (double *)((char *)ctx->coh.ptr + cnt_bytes);
+        coh.sref = coh.lb2 + n;
+    }
+    flags = (flags & ~(unsigned)(ICP_HINT_IDX | ICP_NO_FUSE | ICP_COHERENT)) | (pos ? ICP_INTERNAL_POS : 0u);
     int tail_nb = 0;
     for (int it = 0; it < max_iter; ++it) {
         int32_t *idx = ib[it & 1];
@@ -996,7 +1007,8 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
         int nerr = 0;
         const FusedApply fa = {st->R, st->t, &err_part, &nerr};
         if (int rc = closest_dispatch(ctx, fused ? src : ss, n, tgt, m, dim, first ? flags : (flags | ICP_HINT_IDX), idx, nullptr,
-                                      done, &grid, first ? nullptr : ib[(it - 1) & 1], (fused && !first) ? &fa : nullptr))
+                                      done, &grid, first ? nullptr : ib[(it - 1) & 1], (fused && !first) ? &fa : nullptr,
+                                      coherent ? &coh : nullptr))
             return rc;
         int nb = 0;
         if (int rc = shard_sums(ctx, src, tgt_rows, idx, n, dim, st->cs, st->ct, st->sums, done, &nb)) return rc;

@@ -286,7 +286,7 @@ class RigidComm:
 
 
 def rigid_icp_dist(src_shard, target, tol, run, use_tol=True, compare_sqrt=False, force_brute=False, want_idx=False,
-                   comm=None, ctx=None, no_fuse=False, force_grid=False):
+                   comm=None, ctx=None, no_fuse=False, force_grid=False, coherent=False):
     """Source-sharded ICP through icp_rigid_run_dist.  Every rank passes its rows of the source and the whole target;
     returns dict(T, err_hist, iters[, idx]) of device tensors, T / err_hist / iters identical on all ranks, idx for the
     rank's own rows."""
@@ -304,7 +304,8 @@ def rigid_icp_dist(src_shard, target, tol, run, use_tol=True, compare_sqrt=False
     iters = ctx.empty((1,), torch.int32)
     idx = ctx.empty((src.shape[0],), torch.int32) if want_idx else None
     flags = ((_lib.ICP_COMPARE_SQRT if compare_sqrt else 0) | (_lib.ICP_FORCE_BRUTE if force_brute else 0) |
-             (_lib.ICP_NO_FUSE if no_fuse else 0) | (_lib.ICP_FORCE_GRID if force_grid else 0))
+             (_lib.ICP_NO_FUSE if no_fuse else 0) | (_lib.ICP_FORCE_GRID if force_grid else 0) |
+             (_lib.ICP_COHERENT if coherent else 0))
     comm.error = None
     try:
         ctx.call("icp_rigid_run_dist", ptr(src), src.shape[0], ptr(tgt), tgt.shape[0], dim, ctypes.c_double(float(tol)), run,

@@ -87,8 +87,9 @@ def apply_transform(source, R, t, ctx=None):
 
 
 def rigid_icp(source, target, tol, run, use_tol=True, compare_sqrt=False, force_brute=False, want_idx=False,
-              force_grid=False, ctx=None, no_fuse=False):
-    """Fused ICP loop on the device.  Returns dict(T, err_hist, iters[, idx]) of device tensors."""
+              force_grid=False, ctx=None, no_fuse=False, coherent=False):
+    """Fused ICP loop on the device.  Returns dict(T, err_hist, iters[, idx]) of device tensors.
+    coherent: ICP_COHERENT (icp_hip.h) -- rows whose match is provably unchanged skip the search; same results."""
     ctx = ctx or get_context()
     torch = ctx.torch
     src, tgt, dim = _dims(ctx, source, target)
@@ -101,7 +102,8 @@ def rigid_icp(source, target, tol, run, use_tol=True, compare_sqrt=False, force_
     iters = ctx.empty((1,), torch.int32)
     idx = ctx.empty((src.shape[0],), torch.int32) if want_idx else None
     flags = ((_lib.ICP_COMPARE_SQRT if compare_sqrt else 0) | (_lib.ICP_FORCE_BRUTE if force_brute else 0) |
-             (_lib.ICP_FORCE_GRID if force_grid else 0) | (_lib.ICP_NO_FUSE if no_fuse else 0))
+             (_lib.ICP_FORCE_GRID if force_grid else 0) | (_lib.ICP_NO_FUSE if no_fuse else 0) |
+             (_lib.ICP_COHERENT if coherent else 0))
     tolv = float(tol)
     ctx.call("icp_rigid_run", ptr(src), src.shape[0], ptr(tgt), tgt.shape[0], dim, ctypes.c_double(tolv), run,
              1 if use_tol else 0, flags, ptr(T), ptr(hist), ptr(iters), ptr(idx))

@@ -57,9 +57,15 @@ enum {
     ICP_HINT_IDX = 8u,     /* idx_out holds, on entry, some target index per query (typically the previous
                               iteration's correspondence): the grid search evaluates it first as its starting
                               bound.  The result is the same exact argmin; out-of-range entries are ignored. */
-    ICP_NO_FUSE = 16u      /* icp_rigid_run[_dist]: keep the moved source as an array and run `apply` and the error
+    ICP_NO_FUSE = 16u,     /* icp_rigid_run[_dist]: keep the moved source as an array and run `apply` and the error
                               as kernels of their own instead of inside the grid search (same T and correspondences
                               bit for bit, errors equal up to summation order; for tests and measurements) */
+    ICP_COHERENT = 32u     /* icp_rigid_run[_dist], fused form: every search also leaves, per source row, a lower bound on
+                              the distance to every target OTHER than its match; in the following iterations a row whose
+                              match is still provably the nearest target (triangle inequality on how far the row has moved
+                              since, with slack for every rounding) keeps it without a search.  Same correspondences, T
+                              and errors bit for bit (tests/test_gpu_rigid.py); no counterpart in the reference, whose
+                              Match (icp_3d.py:48-53) scans every target for every row in every iteration. */
 };
 
 const char *icp_last_error(void);

@@ -258,6 +258,44 @@ def test_fused_loop_equals_unfused_loop(rigid, dim, use_tol, n):
     assert torch.equal(a["err_hist"][:k], a2["err_hist"][:k])      # and reproducible bit for bit
 
 
+@pytest.mark.parametrize("dim,use_tol,n,kind", [(3, False, 60000, "normal"), (3, True, 45001, "normal"), (2, False, 50000, "normal"),
+                                                  (3, False, 20000, "lattice"), (3, False, 300000, "rim")])
+def test_coherent_loop_equals_plain_loop(rigid, dim, use_tol, n, kind):
+    """ICP_COHERENT: every search also leaves, per source row, the second-best squared distance (a lower bound for every
+    target but the match); in later iterations a row that has moved by delta since then keeps its match without a search
+    when the match is still nearer than that bound minus delta (triangle inequality, slack for every rounding), and only
+    the other rows are searched.  The proof says the full scan would return the same index, so the whole run -- transform,
+    correspondences, error history, iteration count -- must equal the plain fused loop's bit for bit: on a Gaussian cloud,
+    in 2-D, with the stop test live, on a lattice (masses of exact ties: a tie can never be kept) and on a cloud with a
+    sparse rim and rows that are NaN / inf / far away (never kept, or kept for long).  40 iterations, so that rows are
+    kept, drift, fail the test and are searched again several times over."""
+    import torch
+    rng = np.random.default_rng(60 + dim + n)
+    if kind == "lattice":
+        tgt = rng.integers(0, 24, (n + 3000, dim)).astype(np.float64) * 0.25
+    else:
+        tgt = rng.standard_normal((n + 7000, dim))
+    c, s = np.cos(0.15), np.sin(0.15)
+    R = np.eye(dim)
+    R[:2, :2] = [[c, s], [-s, c]]
+    src = ((tgt - 0.03) @ R)[rng.permutation(len(tgt))[:n]]
+    if kind == "rim":
+        src[:2000] *= 3.0                     # rows far outside the target: deferred pass, large bounds
+        src[5000:5050] = np.nan
+        src[6000:6010] = np.inf
+        src[7000] = 1e12
+    run = 40
+    a = rigid.rigid_icp(src, tgt, 1e-7, run, use_tol=use_tol, want_idx=True, force_grid=True)
+    b = rigid.rigid_icp(src, tgt, 1e-7, run, use_tol=use_tol, want_idx=True, force_grid=True, coherent=True)
+    k = int(a["iters"].cpu()[0])
+    assert k == int(b["iters"].cpu()[0]) and (use_tol or k == run)
+    bits = lambda t: t.contiguous().view(torch.int64)    # (NaN rows make T NaN: compare bit patterns)
+    assert torch.equal(bits(a["T"]), bits(b["T"])) and torch.equal(a["idx"], b["idx"])
+    assert torch.equal(bits(a["err_hist"][:k]), bits(b["err_hist"][:k]))
+    b2 = rigid.rigid_icp(src, tgt, 1e-7, run, use_tol=use_tol, want_idx=True, force_grid=True, coherent=True)   # a second call: no stale state
+    assert torch.equal(bits(b["T"]), bits(b2["T"])) and torch.equal(b["idx"], b2["idx"])
+
+
 def test_large_target_and_sorted_source_are_built_concurrently(rigid):
     """icp_rigid_run builds the Morton order of the source on a side stream while the target's grid is built on the
     main one.  Above 4 M target points the target is ordered by the same radix sort as the source: the two sorts

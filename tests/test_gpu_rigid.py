@@ -336,6 +336,14 @@ def test_fused_loop_equals_bruteforce_at_full_size(api):
     prev = rigid.rigid_icp(sd, td, 0.0, 2, use_tol=False)["T"]
     ss = rigid.apply_transform(sd, prev[:3, :3].contiguous(), prev[3, :3].contiguous())
     assert torch.equal(rigid.closest_indices(ss, td, force_brute=True), a["idx"])
+    # the coherent loop (ICP_COHERENT: rows whose match is provably unchanged skip the search) at the bench's size and
+    # iteration count: the plain loop's transform, correspondences and errors bit for bit, and the full scan's answer
+    p30 = rigid.rigid_icp(sd, td, 0.0, 30, use_tol=False, want_idx=True)
+    c30 = rigid.rigid_icp(sd, td, 0.0, 30, use_tol=False, want_idx=True, coherent=True)
+    assert torch.equal(p30["T"], c30["T"]) and torch.equal(p30["idx"], c30["idx"]) and torch.equal(p30["err_hist"], c30["err_hist"])
+    prev = rigid.rigid_icp(sd, td, 0.0, 29, use_tol=False, coherent=True)["T"]
+    ss = rigid.apply_transform(sd, prev[:3, :3].contiguous(), prev[3, :3].contiguous())
+    assert torch.equal(rigid.closest_indices(ss, td, force_brute=True), c30["idx"])
 
 
 # ---------------------------------------------------------------- icp_rigid_run_dist (source-sharded loop below Python)
