@@ -131,6 +131,7 @@ struct Coherence {
     double *lb2;      // [n]
     double *sref;     // [n, dim]
     uint32_t *count;  // [blocks of the test pass] queries of each block that could not be proven unchanged this iteration
+    uint32_t *gate;   // 0: few unproven rows (eight lanes each) | 1: too many (the whole-cloud search), set per iteration
 };
 int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, const int32_t *qorder, bool le,
                const double *thr, int32_t *idx_out, double *d2_out, const int32_t *done, const int32_t *hint = nullptr,

@@ -486,14 +486,10 @@ __device__ __forceinline__ bool better2(double da, int32_t ia, double db, int32_
     return da < db || (da == db && ia < ib);
 }
 
-#ifndef ICP_COH_G
-#define ICP_COH_G 8
-#endif
-constexpr int kCohG = ICP_COH_G;   // lanes per query in the deferred pass of a coherent iteration (32 / 16 / 8: 60 / 51 / 47 us)
 
 // LE = false: argmin (d2, index).  LE = true: lowest index with d2 <= thr[q].
 // A query the per-lane pass gave up on after `cap` levels: state to resume from
-struct Deferred {
+struct alignas(16) Deferred {   // 64 bytes: four 16-byte accesses
     int32_t q, level, bi;
     uint32_t bp;  // sorted position of the best record so far
     double best;
@@ -535,8 +531,10 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                                                        const double *__restrict__ tv = nullptr,
                                                        double *__restrict__ err_part = nullptr,
                                                        double *__restrict__ lb2_io = nullptr, double *__restrict__ sref_io = nullptr,
-                                                       uint32_t *__restrict__ coh_count = nullptr) {
+                                                       uint32_t *__restrict__ coh_count = nullptr,
+                                                       const uint32_t *__restrict__ gate = nullptr) {
     static_assert(!BND || !LE, "bounds belong to the argmin search");
+    if (gate && *gate == 0u) return;   // (coherent iterations: the whole-cloud search runs only when too few rows were proven)
     static_assert(COH == 0 || (BND && FUSED), "the coherent passes are forms of the fused, bounded search");
     if (done && *done) return;
     // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), each
@@ -970,7 +968,7 @@ __device__ __forceinline__ void unpack_cell(uint32_t v, int *x, int &lvl) {
 constexpr int kSplit = 32;    // a cell above the finest level with more records than this is replaced by its children
 constexpr int kStack = 384;   // cells per group's stack (a cell whose children would not fit is scanned whole)
 
-template <int DIM, bool LE, bool BND = false, int GG = ICP_DEFER_G>
+template <int DIM, bool LE, bool BND = false>
 __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restrict__ recs,
                                                         const uint32_t *__restrict__ start, GridParams gp,
                                                         const double *__restrict__ thr_in, int32_t *__restrict__ idx_out,
@@ -979,26 +977,20 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
                                                         const uint32_t *__restrict__ n_deferred,
                                                         uint32_t *__restrict__ next_counter,
                                                         const uint32_t *__restrict__ inv, int pos_mode, int jump, int split_min,
-                                                        double *__restrict__ lb2_io = nullptr, double *__restrict__ sref_io = nullptr,
-                                                        int nsub = 1, uint32_t sub_cap = 0) {
+                                                        double *__restrict__ lb2_io = nullptr, double *__restrict__ sref_io = nullptr) {
     // the two counters alternate between searches: nobody touches the other one during this search, so it is
     // cleared here for the next search (before the `done` test, so that it is clear whatever that says)
     if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0u;
     if (done && *done) return;
     constexpr int NBR = DIM == 3 ? 27 : 9;
-    constexpr int G = GG;  // lanes per query
+    constexpr int G = ICP_DEFER_G;  // lanes per query
     constexpr uint32_t GMASK = G == 32 ? 0xffffffffu : ((1u << G) - 1u);
     __shared__ uint32_t stk[64 / G][kStack];
     const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
-    // nsub = 1: the one list, its length in n_deferred[0].  Coherent iterations: nsub lists of sub_cap slots (one per block
-    // of the test pass), their lengths in n_deferred[0 .. nsub); list y is served by `gps` consecutive groups in turn
-    const uint32_t NG = gridDim.x * (64 / G), gid = blockIdx.x * (64 / G) + grp;
-    const uint32_t gps = NG >= (uint32_t)nsub ? NG / (uint32_t)nsub : 1u;
-    for (uint32_t sub = gid / gps; sub < (uint32_t)nsub; sub += NG / gps) {
-    const uint32_t nd = n_deferred[sub];
-    const Deferred *__restrict__ dsub = deferred + (size_t)sub * sub_cap;
-    for (uint32_t it = gid % gps; it < nd; it += gps) {
-        const Deferred dq = dsub[it];
+    const uint32_t nd = *n_deferred;
+    const uint32_t ngroups = gridDim.x * (64 / G);
+    for (uint32_t it = blockIdx.x * (64 / G) + grp; it < nd; it += ngroups) {
+        const Deferred dq = deferred[it];
         const int64_t q = dq.q;
         double s[DIM];
 #pragma unroll
@@ -1238,6 +1230,228 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
             }
         }
     }
+}
+
+// Coherent iterations: how many queries could the test pass not prove?  Beyond a share of them the eight-lane pass below
+// costs more than searching the whole cloud (it spends ~8 us of latency per query where the per-lane pass overlaps
+// thousands: break-even near 16 % at 2^20 x 2^20) -- the first iterations of a run, whose steps are still long -- and
+// *gate = 1 sends the iteration through the ordinary fused search instead (which rewrites the same results for the rows
+// that were proven, and refreshes everybody's bound).
+__global__ __launch_bounds__(256) void coh_mode_kernel(const uint32_t *__restrict__ counts, uint32_t nb, uint32_t limit,
+                                                       uint32_t *__restrict__ gate) {
+    __shared__ uint32_t red[256];
+    uint32_t v = 0;
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) v += counts[b];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *gate = red[0] > limit ? 1u : 0u;
+}
+
+// Coherent iterations: the queries the test pass could not prove (grid_query_kernel<COH = 1> left them as Deferred
+// records in one list per block), EIGHT LANES PER QUERY.  Such a query arrives with its old match as the best so far and
+// an upper bound sec0 on its second-best d2, which says at once how far the search must reach: the level whose 3^DIM box
+// passes the gap test with sec0 (level 0 for 97 % of them at 2^20 x 2^20).  The generic deferred pass spends about twelve
+// dependent memory round trips on such a query (27 cells in rounds of G, then their records in steps of G); here the
+// group tests all 3^DIM cells at once (up to four per lane), issues every range lookup together, concatenates the
+// surviving ranges through LDS and reads the records 4 per lane per step: record, ranges, records -- three round trips.
+// Same candidates, same (d2, index) order, cells skipped only on bound > sec0 (>= the best so far), so the argmin is the
+// full scan's; `second` ends as min(second-best d2 found, sec0), a lower bound on every other target's d2 whatever the
+// quality of sec0.  Levels above 1 (sparse rims: coarse cells hold thousands of records and want the descent of
+// grid_defer_kernel) are forwarded to that kernel's list.
+template <int DIM>
+__global__ __launch_bounds__(64) void coh_small_kernel(const double4 *__restrict__ recs, const uint32_t *__restrict__ start,
+                                                       GridParams gp, int32_t *__restrict__ idx_out,
+                                                       const int32_t *__restrict__ done, const Deferred *__restrict__ lists,
+                                                       const uint32_t *__restrict__ counts, uint32_t nsub, uint32_t sub_cap,
+                                                       Deferred *__restrict__ fwd, uint32_t *__restrict__ n_fwd,
+                                                       double *__restrict__ lb2_io, double *__restrict__ sref_io,
+                                                       const uint32_t *__restrict__ gate) {
+    if (done && *done) return;
+    if (*gate != 0u) return;   // too few rows were proven: the whole-cloud search takes this iteration
+    constexpr int G = 8, NGW = 64 / G, NBR = DIM == 3 ? 27 : 9, CPL = (NBR + G - 1) / G, U = 4;
+    __shared__ uint32_t cr0[NGW][NBR + 1], cpre[NGW][NBR + 1];
+    const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+    const uint32_t NG = gridDim.x * NGW, gid = blockIdx.x * NGW + grp;
+    const uint32_t gps = NG >= nsub ? NG / nsub : 1u;
+    for (uint32_t sub = gid / gps; sub < nsub; sub += NG / gps) {
+        const uint32_t nd = counts[sub];
+        for (uint32_t it = gid % gps; it < nd; it += gps) {
+            const Deferred dq = lists[(size_t)sub * sub_cap + it];
+            double s[DIM];
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) s[a] = dq.s[a];
+            const double sec0 = dq.second;
+            int c0[DIM];
+            cell_of<DIM>(s, gp, c0);
+            // the level the search has to reach (the deferred pass's jump, against sec0)
+            int l = 0;
+            bool found = false;
+            for (; l <= 1 && l <= gp.bits; ++l) {
+                const double hl = gp.h * (double)(1 << l);
+                const int ncl = 1 << (gp.bits - l);
+                const double slack_h = hl * 0x1p-20;
+                double mgap = __builtin_inf();
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) {
+                    const int ca = c0[a] >> l;
+                    const double sl = slack_h + (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
+                    if (ca - 1 > 0) {
+                        const double g = s[a] - (gp.mn[a] + (double)(ca - 1) * hl) - sl;
+                        mgap = g < mgap ? g : mgap;
+                    }
+                    if (ca + 2 < ncl) {
+                        const double g = (gp.mn[a] + (double)(ca + 2) * hl) - s[a] - sl;
+                        mgap = g < mgap ? g : mgap;
+                    }
+                }
+                if (mgap == __builtin_inf() || (mgap > 0.0 && sec0 < mgap * mgap)) {   // box covers the grid | everything within sec0 is inside it
+                    found = true;
+                    break;
+                }
+            }
+            if (!found) {   // (group-uniform) a wide ball, or no usable sec0: the generic pass
+                if (lane == 0) fwd[atomicAdd(n_fwd, 1u)] = dq;
+                continue;
+            }
+            const double hv = gp.h * (double)(1 << l);
+            const int nv = 1 << (gp.bits - l);
+            const double slv = hv * 0x1p-20;
+            uint32_t r0[CPL], len[CPL];
+            uint64_t cd[CPL];
+            bool alive[CPL];
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int nb = lane + k * G;
+                bool inside = nb < NBR;
+                int x[DIM];
+                const int off[3] = {nb % 3 - 1, (nb / 3) % 3 - 1, nb / 9 - 1};
+                double bound = 0.0;
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) {
+                    x[a] = (c0[a] >> l) + off[a];
+                    inside = inside && x[a] >= 0 && x[a] < nv;
+                    const double sl = slv + (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
+                    const double lo = gp.mn[a] + (double)x[a] * hv, hi = gp.mn[a] + (double)(x[a] + 1) * hv;
+                    double g = lo - s[a] - sl;
+                    double gh = s[a] - hi - sl;
+                    open_sides(gp, a, x[a], nv, g, gh);
+                    g = gh > g ? gh : g;
+                    g = g > 0.0 ? g : 0.0;
+                    bound = bound + g * g;   // the per-lane pass's bound, same association
+                }
+                alive[k] = inside && !(bound > sec0);
+                if (!inside)
+#pragma unroll
+                    for (int a = 0; a < DIM; ++a) x[a] = 0;
+                cd[k] = (uint64_t)morton<DIM>(x);
+            }
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {   // every lookup in flight before the first use
+                r0[k] = alive[k] ? start[cd[k] << (DIM * l)] : 0u;
+                len[k] = alive[k] ? start[(cd[k] + 1) << (DIM * l)] : 0u;
+            }
+            uint32_t mycells = 0, myrecs = 0;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                len[k] = alive[k] ? len[k] - r0[k] : 0u;
+                mycells += len[k] ? 1u : 0u;
+                myrecs += len[k];
+            }
+            uint32_t ic = mycells, ir = myrecs;   // inclusive scans over the group
+#pragma unroll
+            for (int o = 1; o < G; o <<= 1) {
+                const uint32_t vc = (uint32_t)__shfl_up((int)ic, o, G), vr = (uint32_t)__shfl_up((int)ir, o, G);
+                if (lane >= o) {
+                    ic += vc;
+                    ir += vr;
+                }
+            }
+            const uint32_t nslot = (uint32_t)__shfl((int)ic, G - 1, G), total = (uint32_t)__shfl((int)ir, G - 1, G);
+            lds_wave_sync();   // the previous query's table is dead
+            {
+                uint32_t slot = ic - mycells, pre = ir - myrecs;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k)
+                    if (len[k]) {
+                        cr0[grp][slot] = r0[k];
+                        cpre[grp][slot] = pre;
+                        ++slot;
+                        pre += len[k];
+                    }
+                if (lane == 0) cpre[grp][nslot] = total;
+            }
+            lds_wave_sync();
+            double lb = dq.best, ls = sec0;
+            int32_t li = dq.bi;
+            uint32_t lp = dq.bp;
+            for (uint32_t base = 0; base < total; base += G * U) {
+                uint32_t rp[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t i = base + (uint32_t)(u * G + lane);
+                    ok[u] = i < total;
+                    uint32_t lo = 0, hi = nslot;   // last slot with cpre <= i
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (cpre[grp][mid] <= i) lo = mid;
+                        else hi = mid;
+                    }
+                    rp[u] = ok[u] ? cr0[grp][lo] + (i - cpre[grp][lo]) : 0u;
+                }
+                double4 rc[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) rc[u] = recs[rp[u]];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!ok[u]) continue;
+                    const double dx = rc[u].x - s[0], dy = rc[u].y - s[1];
+                    double d = dx * dx + dy * dy;
+                    if (DIM == 3) {
+                        const double dz = rc[u].z - s[2];
+                        d = d + dz * dz;
+                    }
+                    const int32_t id = (int32_t)__double_as_longlong(rc[u].w);
+                    const bool better = d < lb || (d == lb && id < li);
+                    ls = better ? lb : ((id != li && d < ls) ? d : ls);
+                    if (better) {
+                        lb = d;
+                        li = id;
+                        lp = rp[u];
+                    }
+                }
+            }
+            const double lb_own = lb;
+            const int32_t li_own = li;
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) {
+                const double ob = shfl_xor_f64(lb, o);
+                const int32_t oi = __shfl_xor(li, o, 64);
+                const uint32_t op = (uint32_t)__shfl_xor((int)lp, o, 64);
+                if (ob < lb || (ob == lb && oi < li)) {
+                    lb = ob;
+                    li = oi;
+                    lp = op;
+                }
+            }
+            double c = li_own == li ? ls : lb_own;   // (see grid_defer_kernel)
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) {
+                const double oc = shfl_xor_f64(c, o);
+                c = oc < c ? oc : c;
+            }
+            if (lane == 0) {
+                const int64_t q = dq.q;
+                idx_out[q] = (int32_t)lp;   // coherent loop: sorted positions
+                lb2_io[q] = c;
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) sref_io[q * DIM + a] = s[a];
+            }
+        }
     }
 }
 
@@ -1949,7 +2163,7 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
     double *clb = coh ? coh->lb2 : nullptr, *csr = coh ? coh->sref : nullptr;
     const size_t defer_cap = ctx->defer.cap;
     // (coherent iterations: one region of 256 records per block of the test pass, padded block count)
-    if (int rc = ensure(ctx, ctx->defer, ((size_t)n + (coh ? (size_t)16 * 256 : 0)) * sizeof(Deferred) + 256)) return rc;
+    if (int rc = ensure(ctx, ctx->defer, ((size_t)n * (coh ? 2 : 1) + (coh ? (size_t)16 * 256 : 0)) * sizeof(Deferred) + 256)) return rc;
     if (ctx->defer.cap != defer_cap) ctx->defer_cleared = nullptr;   // reallocated (possibly at the same address)
     // two counters in the header, used alternately: the deferred pass of one search clears the counter of the
     // next, which saves a 4 us memset launch per search (1 % of an iteration at 2^20 points)
@@ -2026,10 +2240,20 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
             std::fprintf(stderr, "coherent iteration: %u of %lld queries searched\n", tot, (long long)n); \
         } \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[1], st); \
-        hipLaunchKernelGGL((grid_defer_kernel<D, false, true, kCohG>), dim3(coh_blocks), dim3(64), 0, st, (const double4 *)gb.recs, \
-                           (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (const Deferred *)dlist, \
-                           (const uint32_t *)coh->count, ndef_next, (const uint32_t *)gb.inv, 1, \
-                           jump_env >= 0 ? jump_env : 1, split_env, clb, csr, (int)nb, 256u); \
+        /* few unproven rows: eight lanes each (the block lists occupy the deferred list's storage from slot 0, forwarded    \
+           records go behind them); many: the ordinary fused search of every row.  One of the two returns at once. */ \
+        hipLaunchKernelGGL(coh_mode_kernel, dim3(1), dim3(256), 0, st, (const uint32_t *)coh->count, (uint32_t)nb, coh_limit, coh->gate); \
+        hipLaunchKernelGGL((coh_small_kernel<D>), dim3(coh_blocks), dim3(64), 0, st, (const double4 *)gb.recs, (const uint32_t *)gb.start, \
+                           gb.gp, idx_out, done, (const Deferred *)dlist, (const uint32_t *)coh->count, (uint32_t)nb, 256u, \
+                           dlist + (size_t)nb * 256, ndef, clb, csr, (const uint32_t *)coh->gate); \
+        hipLaunchKernelGGL((grid_query_kernel<D, false, 256, 4, true, 4, 3, true, 0>), dim3(nb), dim3(256), 0, st, src, n, qorder, (const double4 *)gb.recs, \
+                           (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (long long *)nullptr, cap, dlist + (size_t)nb * 256, ndef, hint, \
+                           (const uint32_t *)gb.inv, (uint32_t)gb.m, 1, xcd_chunk, fR, ft, (double *)ctx->err_part.ptr, clb, csr, (uint32_t *)nullptr, \
+                           (const uint32_t *)coh->gate); \
+        hipLaunchKernelGGL((grid_defer_kernel<D, false, true>), dim3(nb2), dim3(64), 0, st, (const double4 *)gb.recs, \
+                           (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (const Deferred *)(dlist + (size_t)nb * 256), \
+                           (const uint32_t *)ndef, ndef_next, (const uint32_t *)gb.inv, 1, \
+                           jump_env >= 0 ? jump_env : 1, split_env, clb, csr); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
     } while (0)
     static const int list8 = getenv("ICP_GRID_LIST8") ? atoi(getenv("ICP_GRID_LIST8")) : 0;
@@ -2043,6 +2267,9 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
         else ICP_GQ2(D, L, F, 4, 3); \
     } while (0)
     static const bool coh_trace = getenv("ICP_COHERENT_TRACE") != nullptr;
+    // share of unproven rows beyond which an iteration takes the whole-cloud search (ICP_COHERENT_LIMIT, default 0.12)
+    static const double coh_frac = getenv("ICP_COHERENT_LIMIT") ? atof(getenv("ICP_COHERENT_LIMIT")) : 0.12;
+    const uint32_t coh_limit = (uint32_t)std::min<double>(4e9, coh_frac * (double)n);
     static const unsigned coh_blocks = getenv("ICP_COHERENT_BLOCKS") ? (unsigned)atoi(getenv("ICP_COHERENT_BLOCKS")) : 8192u;
     if (coh && fa) {
         if (gb.gp.dim == 3) ICP_GQC(3);

@@ -989,11 +989,12 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
     // coherent loop (ICP_COHERENT, icp_hip.h; grid_query_kernel<BND>): per source row a bound and the position it was taken at
     static const int coh_env = getenv("ICP_COHERENT") ? atoi(getenv("ICP_COHERENT")) : -1;
     const bool coherent = fused && (coh_env >= 0 ? coh_env != 0 : (flags & ICP_COHERENT) != 0);
-    Coherence coh = {nullptr, nullptr, nullptr};
+    Coherence coh = {nullptr, nullptr, nullptr, nullptr};
     if (coherent) {
-        const size_t cnt_bytes = (((size_t)(n + 255) / 256 + 16) * sizeof(uint32_t) + 255) & ~(size_t)255;   // (padded block count)
+        const size_t cnt_bytes = (((size_t)(n + 255) / 256 + 32) * sizeof(uint32_t) + 255) & ~(size_t)255;   // (gate | padded block count)
         if (int rc = ensure(ctx, ctx->coh, cnt_bytes + (size_t)n * (dim + 1) * sizeof(double))) return rc;
-        coh.count = (uint32_t *)ctx->coh.ptr;
+        coh.gate = (uint32_t *)ctx->coh.ptr;
+        coh.count = coh.gate + 16;
         coh.lb2 = (double *)((char *)ctx->coh.ptr + cnt_bytes);
         coh.sref = coh.lb2 + n;
     }

@@ -275,6 +275,8 @@ def test_bench_contract_line():
     e = d["extra"]
     assert len(e["timed_calls_ms_per_step"]) == 3 and e["repeats"]["min_ms_per_step"] <= d["ms_per_step"] <= e["repeats"]["max_ms_per_step"]
     assert e["setup_ms"] is not None
+    # the opt-in coherent loop is reported beside the headline, never as it, and must have returned the plain loop's bits
+    assert e["coherent_loop"]["equals_plain_loop_bit_for_bit"] is True and e["coherent_loop"]["ms_per_step"] > 0
 
 
 def test_bench_multi_gpu_legs_rehearsal():
