@@ -4,7 +4,8 @@ sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/oracle')
 import numpy as np, torch
 import icp_oracle as orc
 from icp_amd import rigid
-src, tgt = orc.make_rigid_cloud(1 << 20, seed=1)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+src, tgt = orc.make_rigid_cloud(n, seed=1)
 sd, td = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
 for k in (2, 3, 5, 30):
     a = rigid.rigid_icp(sd, td, 0.0, k, use_tol=False, want_idx=True)
