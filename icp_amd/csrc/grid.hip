@@ -532,7 +532,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                                                        double *__restrict__ err_part = nullptr,
                                                        double *__restrict__ lb2_io = nullptr, double *__restrict__ sref_io = nullptr,
                                                        uint32_t *__restrict__ coh_count = nullptr,
-                                                       const uint32_t *__restrict__ gate = nullptr) {
+                                                       const uint32_t *__restrict__ gate = nullptr, uint32_t defer_max = 0xffffffffu) {
     static_assert(!BND || !LE, "bounds belong to the argmin search");
     if (gate && *gate == 0u) return;   // (coherent iterations: the whole-cloud search runs only when too few rows were proven)
     static_assert(COH == 0 || (BND && FUSED), "the coherent passes are forms of the fused, bounded search");
@@ -760,12 +760,17 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             eval(recs[hp], hp);
         }
     }
+    bool may_defer = true;
     for (int l = 0; l <= gp.bits; ++l) {
-        if (l >= cap) {
+        if (l >= cap && may_defer) {
             // A few queries (sparse regions, far outliers) need many levels and would hold their whole
             // wave -- and, at the end of the launch, the whole GPU -- for hundreds of microseconds.
             // They are handed to grid_defer_kernel, which gives each of them a wave of its own.
+            // (the list holds a quarter of the queries: a lane that finds it full keeps its query and climbs on by itself --
+            //  slower for its wave, exact either way; grid_defer_kernel reads min(counter, capacity))
             const uint32_t slot = atomicAdd(n_deferred, 1u);
+            may_defer = slot < defer_max;
+            if (may_defer) {
             Deferred dq;
             dq.q = (int32_t)q;
             dq.level = l;
@@ -777,6 +782,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             dq.second = second;
             deferred[slot] = dq;
             return;
+            }
         }
         ++dbg_levels;
         const double hl = gp.h * (double)(1 << l);
@@ -977,7 +983,8 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
                                                         const uint32_t *__restrict__ n_deferred,
                                                         uint32_t *__restrict__ next_counter,
                                                         const uint32_t *__restrict__ inv, int pos_mode, int jump, int split_min,
-                                                        double *__restrict__ lb2_io = nullptr, double *__restrict__ sref_io = nullptr) {
+                                                        double *__restrict__ lb2_io = nullptr, double *__restrict__ sref_io = nullptr,
+                                                        uint32_t defer_max = 0xffffffffu) {
     // the two counters alternate between searches: nobody touches the other one during this search, so it is
     // cleared here for the next search (before the `done` test, so that it is clear whatever that says)
     if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0u;
@@ -987,7 +994,7 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
     constexpr uint32_t GMASK = G == 32 ? 0xffffffffu : ((1u << G) - 1u);
     __shared__ uint32_t stk[64 / G][kStack];
     const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
-    const uint32_t nd = *n_deferred;
+    const uint32_t nd = *n_deferred < defer_max ? *n_deferred : defer_max;   // (lanes that found the list full kept their queries)
     const uint32_t ngroups = gridDim.x * (64 / G);
     for (uint32_t it = blockIdx.x * (64 / G) + grp; it < nd; it += ngroups) {
         const Deferred dq = deferred[it];
@@ -2162,8 +2169,13 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
     }
     double *clb = coh ? coh->lb2 : nullptr, *csr = coh ? coh->sref : nullptr;
     const size_t defer_cap = ctx->defer.cap;
-    // (coherent iterations: one region of 256 records per block of the test pass, padded block count)
-    if (int rc = ensure(ctx, ctx->defer, ((size_t)n * (coh ? 2 : 1) + (coh ? (size_t)16 * 256 : 0)) * sizeof(Deferred) + 256)) return rc;
+    // The list holds a quarter of the queries (1.4 % are deferred at 2^20 x 2^20, a few tens of per cent on sheets and rims; a
+    // lane that finds it full keeps its query): 16 bytes of scratch per query instead of 64.  Coherent iterations: one region
+    // of 256 records per block of the test pass (padded block count) and, behind them, a full-size list for the forwarded
+    // queries and the whole-cloud search.
+    const size_t defer_slots = coh ? (size_t)n : (size_t)n / 4 + 4096;
+    const uint32_t defer_max = (uint32_t)std::min<size_t>(defer_slots, 0xfffffff0u);
+    if (int rc = ensure(ctx, ctx->defer, (defer_slots + (coh ? (size_t)n + 16 * 256 : 0)) * sizeof(Deferred) + 256)) return rc;
     if (ctx->defer.cap != defer_cap) ctx->defer_cleared = nullptr;   // reallocated (possibly at the same address)
     // two counters in the header, used alternately: the deferred pass of one search clears the counter of the
     // next, which saves a 4 us memset launch per search (1 % of an iteration at 2^20 points)
@@ -2214,13 +2226,13 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
         hipLaunchKernelGGL((grid_query_kernel<D, L, 256, 4, F, LN, UN, B>), dim3(nb), dim3(256), 0, st, src, n, qorder, (const double4 *)gb.recs, \
                            (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, g_grid_dbg, cap, dlist, ndef, hint, \
                            (const uint32_t *)gb.inv, (uint32_t)gb.m, pos_mode ? 1 : 0, xcd_chunk, fR, ft, \
-                           fa ? (double *)ctx->err_part.ptr : (double *)nullptr, clb, csr); \
+                           fa ? (double *)ctx->err_part.ptr : (double *)nullptr, clb, csr, (uint32_t *)nullptr, (const uint32_t *)nullptr, defer_max); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[1], st); \
         if (cap < 1000) \
             hipLaunchKernelGGL((grid_defer_kernel<D, L, B>), dim3(nb2), dim3(64), 0, st, (const double4 *)gb.recs, \
                                (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (const Deferred *)dlist, \
                                (const uint32_t *)ndef, ndef_next, (const uint32_t *)gb.inv, pos_mode ? 1 : 0, \
-                               jump_env >= 0 ? jump_env : ((hint && pos_mode) ? 1 : 0), split_env, clb, csr); \
+                               jump_env >= 0 ? jump_env : ((hint && pos_mode) ? 1 : 0), split_env, clb, csr, defer_max); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
     } while (0)
 #define ICP_GQ2(D, L, F, LN, UN) ICP_GQ3(D, L, F, LN, UN, false)

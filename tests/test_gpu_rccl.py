@@ -49,6 +49,18 @@ def test_rigid_loop_over_library_rccl(rccl, n, no_fuse):
     np.testing.assert_allclose(b["err_hist"].cpu().numpy()[:iters], ref["err_hist"].cpu().numpy()[:iters], rtol=1e-12)
 
 
+def test_coherent_sharded_loop_over_library_rccl(rccl):
+    """ICP_COHERENT inside icp_rigid_run_dist (the same loop): with every collective issued (one rank, the library's own
+    communicator) the coherent run returns the plain sharded run's transform, errors and correspondences bit for bit."""
+    from icp_amd.dist import RigidComm, rigid_icp_dist
+    src, tgt = orc.make_rigid_cloud(200000, seed=6)
+    run = 25
+    a = rigid_icp_dist(src, tgt, 0.0, run, use_tol=False, want_idx=True, comm=RigidComm("cuda:0", world=1, rccl=rccl, force=True))
+    b = rigid_icp_dist(src, tgt, 0.0, run, use_tol=False, want_idx=True, comm=RigidComm("cuda:0", world=1, rccl=rccl, force=True), coherent=True)
+    for k in ("T", "err_hist", "iters", "idx"):
+        assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy()), k
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_nicp_solve_over_library_rccl(rccl, monkeypatch, graph):
     from icp_amd import nicp, nicp_dist as nd
