@@ -984,7 +984,20 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
                                                         uint32_t *__restrict__ next_counter,
                                                         const uint32_t *__restrict__ inv, int pos_mode, int jump, int split_min,
                                                         double *__restrict__ lb2_io = nullptr, double *__restrict__ sref_io = nullptr,
-                                                        uint32_t defer_max = 0xffffffffu) {
+                                                        uint32_t defer_max = 0xffffffffu,
+                                                        const uint32_t *__restrict__ mode_counts = nullptr, uint32_t mode_nb = 0,
+                                                        uint32_t mode_limit = 0, uint32_t *__restrict__ gate_out = nullptr) {
+    // Coherent iterations: how many rows could this iteration's test pass not prove?  Beyond a share of them the eight-lane
+    // pass costs more than searching the whole cloud (it spends ~10 us of latency per row where the per-lane pass overlaps
+    // thousands: break-even near 16 % at 2^20 x 2^20), and the NEXT iteration takes the ordinary fused search instead
+    // (*gate_out = 1; a lag of one iteration: the share changes slowly, and either form returns the same results).  The
+    // last block sums the counts -- it has no query of its own unless the list is nearly full.
+    if (mode_counts && blockIdx.x == gridDim.x - 1) {
+        uint32_t v = 0;
+        for (uint32_t b = threadIdx.x; b < mode_nb; b += 64) v += mode_counts[b];
+        for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_down((int)v, o, 64);
+        if (threadIdx.x == 0) *gate_out = v > mode_limit ? 1u : 0u;
+    }
     // the two counters alternate between searches: nobody touches the other one during this search, so it is
     // cleared here for the next search (before the `done` test, so that it is clear whatever that says)
     if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0u;
@@ -1239,25 +1252,6 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
     }
 }
 
-// Coherent iterations: how many queries could the test pass not prove?  Beyond a share of them the eight-lane pass below
-// costs more than searching the whole cloud (it spends ~8 us of latency per query where the per-lane pass overlaps
-// thousands: break-even near 16 % at 2^20 x 2^20) -- the first iterations of a run, whose steps are still long -- and
-// *gate = 1 sends the iteration through the ordinary fused search instead (which rewrites the same results for the rows
-// that were proven, and refreshes everybody's bound).
-__global__ __launch_bounds__(256) void coh_mode_kernel(const uint32_t *__restrict__ counts, uint32_t nb, uint32_t limit,
-                                                       uint32_t *__restrict__ gate) {
-    __shared__ uint32_t red[256];
-    uint32_t v = 0;
-    for (uint32_t b = threadIdx.x; b < nb; b += 256) v += counts[b];
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *gate = red[0] > limit ? 1u : 0u;
-}
-
 // Coherent iterations: the queries the test pass could not prove (grid_query_kernel<COH = 1> left them as Deferred
 // records in one list per block), EIGHT LANES PER QUERY.  Such a query arrives with its old match as the best so far and
 // an upper bound sec0 on its second-best d2, which says at once how far the search must reach: the level whose 3^DIM box
@@ -1270,7 +1264,7 @@ __global__ __launch_bounds__(256) void coh_mode_kernel(const uint32_t *__restric
 // quality of sec0.  Levels above 1 (sparse rims: coarse cells hold thousands of records and want the descent of
 // grid_defer_kernel) are forwarded to that kernel's list.
 template <int DIM>
-__global__ __launch_bounds__(64) void coh_small_kernel(const double4 *__restrict__ recs, const uint32_t *__restrict__ start,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void coh_small_kernel(const double4 *__restrict__ recs, const uint32_t *__restrict__ start,
                                                        GridParams gp, int32_t *__restrict__ idx_out,
                                                        const int32_t *__restrict__ done, const Deferred *__restrict__ lists,
                                                        const uint32_t *__restrict__ counts, uint32_t nsub, uint32_t sub_cap,
@@ -1279,15 +1273,17 @@ __global__ __launch_bounds__(64) void coh_small_kernel(const double4 *__restrict
                                                        const uint32_t *__restrict__ gate) {
     if (done && *done) return;
     if (*gate != 0u) return;   // too few rows were proven: the whole-cloud search takes this iteration
-    constexpr int G = 8, NGW = 64 / G, NBR = DIM == 3 ? 27 : 9, CPL = (NBR + G - 1) / G, U = 4;
+    constexpr int G = 8, NGW = 64 / G, NBR = DIM == 3 ? 27 : 9, CPL = (NBR + G - 1) / G, U = 3;
     __shared__ uint32_t cr0[NGW][NBR + 1], cpre[NGW][NBR + 1];
     const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
     const uint32_t NG = gridDim.x * NGW, gid = blockIdx.x * NGW + grp;
     const uint32_t gps = NG >= nsub ? NG / nsub : 1u;
     for (uint32_t sub = gid / gps; sub < nsub; sub += NG / gps) {
+        // (the first record is fetched together with the list's length: the slot exists whatever the length says)
+        uint32_t it = gid % gps;
+        Deferred dq = lists[(size_t)sub * sub_cap + (it < sub_cap ? it : 0u)];
         const uint32_t nd = counts[sub];
-        for (uint32_t it = gid % gps; it < nd; it += gps) {
-            const Deferred dq = lists[(size_t)sub * sub_cap + it];
+        for (; it < nd; it += gps, dq = lists[(size_t)sub * sub_cap + (it < nd ? it : 0u)]) {
             double s[DIM];
 #pragma unroll
             for (int a = 0; a < DIM; ++a) s[a] = dq.s[a];
@@ -1396,19 +1392,29 @@ __global__ __launch_bounds__(64) void coh_small_kernel(const double4 *__restrict
             int32_t li = dq.bi;
             uint32_t lp = dq.bp;
             for (uint32_t base = 0; base < total; base += G * U) {
+                // a lane takes U CONSECUTIVE records of the concatenation (one 128-byte line when they lie in one cell): one
+                // search of the table for the first, a walk along it for the others
                 uint32_t rp[U];
                 bool ok[U];
+                const uint32_t i0 = base + (uint32_t)(lane * U);
+                uint32_t lo = 0, hi = nslot;   // last slot with cpre <= i0
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (cpre[grp][mid] <= i0) lo = mid;
+                    else hi = mid;
+                }
+                uint32_t cbeg = cpre[grp][lo], cend = cpre[grp][lo + 1], cr = cr0[grp][lo];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const uint32_t i = base + (uint32_t)(u * G + lane);
+                    const uint32_t i = i0 + (uint32_t)u;
                     ok[u] = i < total;
-                    uint32_t lo = 0, hi = nslot;   // last slot with cpre <= i
-                    while (hi - lo > 1) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (cpre[grp][mid] <= i) lo = mid;
-                        else hi = mid;
+                    while (ok[u] && i >= cend) {   // (slots hold at least one record: at most U - 1 steps in all)
+                        ++lo;
+                        cbeg = cend;
+                        cend = cpre[grp][lo + 1];
+                        cr = cr0[grp][lo];
                     }
-                    rp[u] = ok[u] ? cr0[grp][lo] + (i - cpre[grp][lo]) : 0u;
+                    rp[u] = ok[u] ? cr + (i - cbeg) : 0u;
                 }
                 double4 rc[U];
 #pragma unroll
@@ -2254,7 +2260,6 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
         if (g_grid_events) (void)hipEventRecord(g_grid_events[1], st); \
         /* few unproven rows: eight lanes each (the block lists occupy the deferred list's storage from slot 0, forwarded    \
            records go behind them); many: the ordinary fused search of every row.  One of the two returns at once. */ \
-        hipLaunchKernelGGL(coh_mode_kernel, dim3(1), dim3(256), 0, st, (const uint32_t *)coh->count, (uint32_t)nb, coh_limit, coh->gate); \
         hipLaunchKernelGGL((coh_small_kernel<D>), dim3(coh_blocks), dim3(64), 0, st, (const double4 *)gb.recs, (const uint32_t *)gb.start, \
                            gb.gp, idx_out, done, (const Deferred *)dlist, (const uint32_t *)coh->count, (uint32_t)nb, 256u, \
                            dlist + (size_t)nb * 256, ndef, clb, csr, (const uint32_t *)coh->gate); \
@@ -2265,7 +2270,7 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
         hipLaunchKernelGGL((grid_defer_kernel<D, false, true>), dim3(nb2), dim3(64), 0, st, (const double4 *)gb.recs, \
                            (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (const Deferred *)(dlist + (size_t)nb * 256), \
                            (const uint32_t *)ndef, ndef_next, (const uint32_t *)gb.inv, 1, \
-                           jump_env >= 0 ? jump_env : 1, split_env, clb, csr); \
+                           jump_env >= 0 ? jump_env : 1, split_env, clb, csr, 0xffffffffu, (const uint32_t *)coh->count, (uint32_t)nb, coh_limit, coh->gate); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
     } while (0)
     static const int list8 = getenv("ICP_GRID_LIST8") ? atoi(getenv("ICP_GRID_LIST8")) : 0;
@@ -2282,7 +2287,7 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
     // share of unproven rows beyond which an iteration takes the whole-cloud search (ICP_COHERENT_LIMIT, default 0.12)
     static const double coh_frac = getenv("ICP_COHERENT_LIMIT") ? atof(getenv("ICP_COHERENT_LIMIT")) : 0.12;
     const uint32_t coh_limit = (uint32_t)std::min<double>(4e9, coh_frac * (double)n);
-    static const unsigned coh_blocks = getenv("ICP_COHERENT_BLOCKS") ? (unsigned)atoi(getenv("ICP_COHERENT_BLOCKS")) : 8192u;
+    static const unsigned coh_blocks = getenv("ICP_COHERENT_BLOCKS") ? (unsigned)atoi(getenv("ICP_COHERENT_BLOCKS")) : 10240u;   // (5120 / 8192 / 10240: 34.8 / 32.7 / 30.2 us)
     if (coh && fa) {
         if (gb.gp.dim == 3) ICP_GQC(3);
         else ICP_GQC(2);

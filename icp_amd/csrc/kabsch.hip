@@ -995,6 +995,7 @@ static int rigid_loop(icp_ctx *ctx, const double *src, int64_t n, const double *
         if (int rc = ensure(ctx, ctx->coh, cnt_bytes + (size_t)n * (dim + 1) * sizeof(double))) return rc;
         coh.gate = (uint32_t *)ctx->coh.ptr;
         coh.count = coh.gate + 16;
+        ICP_HIP_CHECK(hipMemsetAsync(coh.gate, 0, sizeof(uint32_t), ctx->stream));   // (the first coherent iteration: eight-lane form)
         coh.lb2 = (double *)((char *)ctx->coh.ptr + cnt_bytes);
         coh.sref = coh.lb2 + n;
     }
