@@ -65,7 +65,7 @@ def ICP(source, target, tol, run):
     """Rigid ICP; returns the (dim+1)x(dim+1) row-vector matrix T (icp_3d.py:102-121).
     Prints the reference's per-iteration line `err = %f (%2d)` (icp_3d.py:115)."""
     as_np = _is_np(source, target)
-    r = rigid.rigid_icp(source, target, tol, run)
+    r = rigid.rigid_icp(source, target, tol, run, coherent=len(source) >= rigid.COHERENT_MIN_ROWS)
     n = int(r["iters"].cpu()[0])
     for i, e in enumerate(r["err_hist"].cpu().numpy()[:n]):
         print("err = %f (%2d)" % (e, i))

@@ -23,7 +23,7 @@ def ICP(source, target, tol, run):
     """Runs all `run` iterations (the reference stops only on user input) and returns T
     (the reference returns nothing; the matrix is what its last iteration computed)."""
     as_np = _is_np(source, target)
-    r = rigid.rigid_icp(source, target, tol, run, use_tol=False)
+    r = rigid.rigid_icp(source, target, tol, run, use_tol=False, coherent=len(source) >= rigid.COHERENT_MIN_ROWS)
     for i, e in enumerate(r["err_hist"].cpu().numpy()):
         print("err = %f (%2d)" % (e, i))
     return _out(r["T"], as_np)

@@ -86,6 +86,11 @@ def apply_transform(source, R, t, ctx=None):
     return out
 
 
+# from this many source rows on the hosts that mirror the reference's ICP() turn ICP_COHERENT on by themselves: the same
+# results bit for bit, no gain below ~1e5 rows; rigid_icp itself keeps the flag explicit
+COHERENT_MIN_ROWS = 131072
+
+
 def rigid_icp(source, target, tol, run, use_tol=True, compare_sqrt=False, force_brute=False, want_idx=False,
               force_grid=False, ctx=None, no_fuse=False, coherent=False):
     """Fused ICP loop on the device.  Returns dict(T, err_hist, iters[, idx]) of device tensors.

@@ -346,6 +346,23 @@ def test_fused_loop_equals_bruteforce_at_full_size(api):
     assert torch.equal(rigid.closest_indices(ss, td, force_brute=True), c30["idx"])
 
 
+def test_host_icp_turns_the_coherent_loop_on_for_large_clouds(api, capsys):
+    """icp_3d.ICP / icp_row.ICP (the reference's entry points, icp_3d.py:102-121) pass ICP_COHERENT from 131 072 source rows
+    on: the transform and the printed error lines are the plain loop's bit for bit."""
+    rigid = api["rigid"]
+    src, tgt = orc.make_rigid_cloud(150000, seed=9)
+    assert len(src) >= rigid.COHERENT_MIN_ROWS
+    ref = rigid.rigid_icp(src, tgt, 1e-4, 20)
+    capsys.readouterr()
+    T = api["icp_3d"].ICP(src, tgt, 1e-4, 20)
+    lines = capsys.readouterr().out.strip().splitlines()
+    k = int(ref["iters"].cpu()[0])
+    assert np.array_equal(T, ref["T"].cpu().numpy())
+    assert lines == ["err = %f (%2d)" % (e, i) for i, e in enumerate(ref["err_hist"].cpu().numpy()[:k])]
+    T2 = api["icp_row"].ICP(src, tgt, 0.0, 12)
+    assert np.array_equal(T2, rigid.rigid_icp(src, tgt, 0.0, 12, use_tol=False)["T"].cpu().numpy())
+
+
 # ---------------------------------------------------------------- icp_rigid_run_dist (source-sharded loop below Python)
 @pytest.mark.parametrize("n,m,tol,run,dim", [(60000, 50000, 0.10, 50, 3), (40000, 45000, -np.inf, 7, 3), (3000, 2500, 0.05, 30, 2),
                                              (500, 700, 0.10, 50, 3)])
