@@ -31,6 +31,16 @@ def test_header_symbols_exported():
     assert lib.icp_version() >= 100
 
 
+def test_flag_values_match_the_header():
+    """The Python host's flag constants are the header's enumerators (ICP_COHERENT joined them in round 3)."""
+    from icp_amd import _lib
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    vals = {k: int(v) for k, v in re.findall(r"\b(ICP_[A-Z_]+)\s*=\s*(\d+)u", text)}
+    for name in ("ICP_COMPARE_SQRT", "ICP_FORCE_BRUTE", "ICP_FORCE_GRID", "ICP_HINT_IDX", "ICP_NO_FUSE", "ICP_COHERENT"):
+        assert vals[name] == getattr(_lib, name), name
+    assert len({vals[n] for n in vals if n in dir(_lib)}) >= 6          # distinct bits
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
