@@ -1921,6 +1921,7 @@ struct FusedCg {
     double *x_tail, *r_tail, *zb_tail, *Ap_tail;
     const double *p_tail;
     int parity;  // which Scal::tmp slot holds r.z (see above); -1: the direction stage is NOT fused, r.z is Scal::rz
+    const double *mom;  // direction kernel, enriched space fused (RICHF): the update kernel's block moment rows
 };
 
 template <int DIM, bool FUSED, bool RICH, bool P32>
@@ -2111,13 +2112,18 @@ struct FitArgs {
 // iteration.  A fit row needs p_new of the vertex's 4 influence neighbours, which other threads of this launch are
 // only just computing -- each thread recomputes them from the neighbours' zb, p_old, P, v by the same operations in
 // the same order (so the rows are bit-identical to fitrow_kernel's), which is why p_new goes to a second buffer.
-template <int DIM, bool FUSED, bool FIT, bool COMPAT>
+// RICHF (round 3): the FUSED form for the ENRICHED coarse space (meshes <= 65 536 vertices, one GPU): every block sums the
+// update kernel's two scalar slots and its 60 moment columns and solves the 66 x 66 coarse system itself, in the order of
+// cg_sum_coarse_kernel's 1024-thread block (16 row groups per moment column, 8 column chunks per row of E+) so that the
+// iteration keeps its bits; that kernel -- a single block, 10 us of dependent latencies at 10 k vertices -- is not launched.
+template <int DIM, bool FUSED, bool FIT, bool COMPAT, bool RICHF = false>
 __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, const Coarse *__restrict__ coarse,
                                                         const double *__restrict__ P, const double *__restrict__ v, int64_t n,
                                                         const double *__restrict__ zb, double *__restrict__ p, int64_t nown,
                                                         Strides st, FusedCg f, PolyBasis pb, FitArgs fa) {
     constexpr int S = Lay<DIM>::S, NG = Lay<DIM>::NG;
-    const int nm = FUSED ? NG : NG * pb.M;  // vertex-mode columns of Z (the fused kernels serve the plain space only)
+    const int nm = FUSED ? NG : NG * pb.M;  // vertex-mode columns of Z (FUSED serves the plain space, RICHF the enriched one)
+    static_assert(!(FUSED && RICHF), "one fused form at a time");
     __shared__ double y_s[NZMAX];
     double beta;
     // the vertex's own blocks first: their latency overlaps the (fused) reduction prologue (see cg_update_prec_kernel)
@@ -2186,6 +2192,102 @@ __global__ __launch_bounds__(NB) void cg_dir_prec_kernel(Scal *__restrict__ s, c
             double rz = acc_s[0];
             const double rr = acc_s[1];
             for (int a = 0; a < nz; ++a) rz += ztr_s[a] * y_s[a];
+            const double bt = rz / rzold0;
+            const bool done = !(rr > tol20 * rr00) && !(rz > tol2z0 * rz00);
+            if (blockIdx.x == 0) {
+                s->rz_new = rz;
+                s->rr = rr;
+                s->beta = bt;
+                s->rz = rz;
+                s->tmp[f.parity ^ 1] = rz;
+                s->iters += 1;
+                if (done) s->stop = 1;
+            }
+            beta_sh = bt;
+            if (done) stop_sh = 1;
+        }
+        __syncthreads();
+        if (stop_sh) return;  // uniform over the block
+        beta = beta_sh;
+    } else if constexpr (RICHF) {
+        const int nz = nm + NG;
+        __shared__ double tot_s[kSumSlots], ztr_s[NZMAX], acc_s[2];
+        __shared__ double beta_sh;
+        __shared__ int stop_sh;
+        int stop0 = 0;
+        double rt0[NG], zt0[NG], rzold0 = 0.0, tol20 = 0.0, rr00 = 0.0, tol2z0 = 0.0, rz00 = 0.0;
+        if (threadIdx.x == 0) {   // scalars, fetched before the sums they meet
+            stop0 = s->stop;
+            rzold0 = s->tmp[f.parity];
+            tol20 = coarse->tol2;
+            rr00 = s->rr0;
+            tol2z0 = coarse->tol2z;
+            rz00 = s->rz0;
+            for (int k = 0; k < NG; ++k) {
+                rt0[k] = f.r_tail[k];
+                zt0[k] = f.zb_tail[k];
+            }
+        }
+        // moment columns: thread = column; block_rows_sum_wide's order (row group g = rows g, g + 16, ... ascending, then the
+        // 16 group sums in order), 64 rows in flight
+        if (threadIdx.x < kMomSlots && threadIdx.x < nm) {
+            double a[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] = 0.0;
+            for (int b0 = 0; b0 < f.nb; b0 += 64) {
+                double t[64];
+#pragma unroll
+                for (int u = 0; u < 64; ++u) t[u] = b0 + u < f.nb ? f.mom[(int64_t)(b0 + u) * kMomSlots + threadIdx.x] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 64; ++u)
+                    if (b0 + u < f.nb) a[u & 15] += t[u];
+            }
+            double sv = a[0];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) sv += a[q];
+            ztr_s[threadIdx.x] = sv;
+        }
+        block_rows_sum_lds<0x3u>(f.in_partial, f.nb, tot_s);
+        __syncthreads();
+        if (threadIdx.x == 0) {  // coarse_logic (tails advanced by the update kernel), by every block for itself
+            const int stop = stop0;
+            if (!stop) {
+                double rz = tot_s[0], rr = tot_s[1];
+                for (int k = 0; k < NG; ++k) {
+                    const double rt = rt0[k], zt = zt0[k];
+                    rz += rt * zt;
+                    rr += rt * rt;
+                    ztr_s[nm + k] = rt;
+                }
+                acc_s[0] = rz;
+                acc_s[1] = rr;
+            }
+            stop_sh = stop;
+        }
+        __syncthreads();
+        if (!stop_sh) {
+            // y = E+ Z^T r: a row's 8 column chunks in order, as the 1024-thread block adds them
+            const int per = (nz + 7) / 8;
+            for (int row = threadIdx.x; row < nz; row += blockDim.x) {
+                double y = 0.0;
+                for (int ch = 0; ch < 8; ++ch) {
+                    const int b1 = (ch + 1) * per < nz ? (ch + 1) * per : nz;
+                    double yp = 0.0;
+                    for (int b = ch * per; b < b1; ++b) yp += coarse->Einv[b * nz + row] * ztr_s[b];
+                    y = ch == 0 ? yp : y + yp;
+                }
+                y_s[row] = y;
+            }
+        }
+        __syncthreads();
+        double zy = 0.0;
+        if (!stop_sh && threadIdx.x < 64) {
+            zy = (int)threadIdx.x < nz ? ztr_s[threadIdx.x] * y_s[threadIdx.x] : 0.0;
+            if ((int)threadIdx.x + 64 < nz) zy += ztr_s[threadIdx.x + 64] * y_s[threadIdx.x + 64];
+            zy = wave_sum(zy);
+        }
+        if (threadIdx.x == 0 && !stop_sh) {
+            const double rz = acc_s[0] + zy, rr = acc_s[1];
             const double bt = rz / rzold0;
             const bool done = !(rr > tol20 * rr00) && !(rz > tol2z0 * rz00);
             if (blockIdx.x == 0) {
@@ -3372,7 +3474,11 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
             if (int rc = cg_reset(-1.0, w.grad)) return rc;
             const double *lamd2_tail = w.lamd2 + d.n * d.S;
             const bool fused = !par.sharded() && fused_enabled && !rich;  // see FusedCg (plain coarse space only)
-            const bool mixed = !par.sharded() && fused_enabled && rich;   // enriched space: alpha stage fused, coarse stage its own launch
+            const bool mixed = !par.sharded() && fused_enabled && rich;   // enriched space: alpha stage fused ...
+            // (off by default: measured SLOWER -- whole C3 schedule 4.63 -> 5.53 s, same 110 991 iterations bit for bit: 157 blocks
+            //  of 64 threads each re-summing 157 x 60 moments cost more than the one 1024-thread block they replace)
+            static const int richf_env = getenv("ICP_NICP_FUSEDRICH") ? atoi(getenv("ICP_NICP_FUSEDRICH")) : 0;
+            const bool richf = mixed && richf_env != 0 && !dirfit;        // ... and the coarse stage too (RICHF), or its own launch
             // slots of the update kernel's partial rows that the sums read: r.zb, r.r (+ the NG plain moments)
             const unsigned upd_mask = rich ? 0x3u : (1u << (2 + d.NG)) - 1u;
             hipEvent_t *pev = nullptr;  // nicp_profile_cg: events after every launch of an iteration
@@ -3380,17 +3486,18 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                 if (pev) (void)hipEventRecord(pev[k], st);
             };
             auto precondition = [&](int init, int parity) -> int {
-                const bool fz = fused && !init;            // both stages fused (plain coarse space)
+                const bool fz = (fused || richf) && !init;  // both stages fused
                 const bool fzu = (fused || mixed) && !init;  // the update kernel derives alpha itself
                 double *pk = pbuf[pcur], *p_tail = pk + d.n * d.S;
-                FusedCg fa = {w.partial, nbj, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, fused ? parity : -1};
-                FusedCg fb = {w.partial2, nbv, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, parity};
+                FusedCg fa = {w.partial, nbj, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, (fused || richf) ? parity : -1, nullptr};
+                FusedCg fb = {w.partial2, nbv, lamd2_tail, x_tail, r_tail, zb_tail, Ap_tail, p_tail, parity, w.mom};
                 FitArgs fit = {g->nbr, g->wt, g->k, compat ? w.dd : w.pre, w.glob, c[0], w.y, pbuf[pcur ^ 1], w.rw};
                 double *upd_partial = fzu ? w.partial2 : w.partial;
 #define NICP_UPD(D, F) if (rich) { if (prec32) NICP_UPD2(D, F, true, true); else NICP_UPD2(D, F, true, false); } else { if (prec32) NICP_UPD2(D, F, false, true); else NICP_UPD2(D, F, false, false); }
 #define NICP_UPD2(D, F, R, Q) hipLaunchKernelGGL((cg_update_prec_kernel<D, F, R, Q>), dim3(nbv), dim3(g->vb), 0, st, w.scal, (const double *)x, v, d.n, w.delta, w.rcg, w.z, (const double *)pk, (const double *)w.Ap, (const double *)w.binv, upd_partial, nown, w.st, (const Coarse *)w.coarse, fa, w.mom, w.pb)
 #define NICP_DIR2(D, F, T, C) hipLaunchKernelGGL((cg_dir_prec_kernel<D, F, T, C>), dim3(nbt), dim3(g->vb), 0, st, w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, pk, nown, w.st, fb, w.pb, fit)
 #define NICP_DIR(D, F) do { if (dirfit) { if (compat) NICP_DIR2(D, F, true, true); else NICP_DIR2(D, F, true, false); } else NICP_DIR2(D, F, false, false); } while (0)
+#define NICP_DIRR(D) hipLaunchKernelGGL((cg_dir_prec_kernel<D, false, false, false, true>), dim3(nbt), dim3(g->vb), 0, st, w.scal, (const Coarse *)w.coarse, (const double *)x, v, d.n, (const double *)w.z, pk, nown, w.st, fb, w.pb, fit)
                 if (g->dim == 3) { if (fzu) { NICP_UPD(3, true); } else { NICP_UPD(3, false); } }
                 else { if (fzu) { NICP_UPD(2, true); } else { NICP_UPD(2, false); } }
                 mark(4);
@@ -3408,12 +3515,14 @@ static int solve_impl(icp_ctx *ctx, nicp_graph *g, Work &w, const Par &par_in, d
                                        (const double *)p_tail, (const double *)Ap_tail, w.coarse, w.scal, init, nm);
                 }
                 mark(5);
-                if (g->dim == 3) { if (fz) NICP_DIR(3, true); else NICP_DIR(3, false); }
+                if (fz && richf) { if (g->dim == 3) NICP_DIRR(3); else NICP_DIRR(2); }
+                else if (g->dim == 3) { if (fz) NICP_DIR(3, true); else NICP_DIR(3, false); }
                 else { if (fz) NICP_DIR(2, true); else NICP_DIR(2, false); }
                 mark(6);
 #undef NICP_UPD
 #undef NICP_UPD2
 #undef NICP_DIR
+#undef NICP_DIRR
 #undef NICP_DIR2
                 if (dirfit) pcur ^= 1;  // the new direction (and its fit rows, in w.y) are in the other buffer
                 return exchange(ctx, g, w, par, pbuf[pcur]);
