@@ -176,7 +176,26 @@ def leg_c4(args, ctx, comm, lib_rccl, world, rank, barrier):
     ok = torch.equal(rigid.closest_indices(ss, t_d, force_brute=True, ctx=ctx), res["idx"][take])
     flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    return {"workload": "C4: rigid ICP %d x %d fp64 points (seed 2), source rows sharded over %d ranks, target replicated, "
+    # the same call with ICP_COHERENT (rows whose match is provably unchanged skip the search): beside the
+    # plain figure, never instead of it; must return the plain run's bits on every rank
+    coh = None
+    try:
+        run4c = lambda k: rigid_icp_dist(s_d, t_d, 0.0, k, use_tol=False, want_idx=True, comm=cm, ctx=ctx, coherent=True)
+        run4c(2)
+        barrier()
+        t0 = time.perf_counter()
+        resc = run4c(K4)
+        barrier()
+        dtc = _max_over_ranks(time.perf_counter() - t0, args.share_gpu)
+        same = torch.equal(resc["T"], res["T"]) and torch.equal(resc["idx"], res["idx"]) and torch.equal(resc["err_hist"], res["err_hist"])
+        f2 = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
+        dist.all_reduce(f2, op=dist.ReduceOp.MIN)
+        coh = {"seconds": dtc, "ms_per_step": dtc / K4 * 1e3, "queries_per_s": n4 * K4 / dtc,
+               "equals_plain_run_bit_for_bit": bool(float(f2.cpu()[0]) == 1.0)}
+    except Exception as e:  # pragma: no cover
+        coh = {"error": repr(e)}
+    return {"coherent_loop": coh,
+            "workload": "C4: rigid ICP %d x %d fp64 points (seed 2), source rows sharded over %d ranks, target replicated, "
                         "%d iterations in one icp_rigid_run_dist call incl. grid build + Morton sort" % (n4, n4, world, K4),
             "seconds": dt, "ms_per_step": dt / K4 * 1e3, "queries_per_s": n4 * K4 / dt, "icp_iters_per_s": K4 / dt,
             "rows_per_rank": int(n_loc), "collectives_per_iteration": 1, "doubles_per_collective": 17,

@@ -299,6 +299,7 @@ def test_bench_multi_gpu_legs_rehearsal():
     assert "error" not in c4 and "error" not in c5, (c4, c5)
     assert c4["check_idx_equal_bruteforce"] is True and c4["rows_per_rank"] == 131072 and c4["queries_per_s"] > 0
     assert c4["host_callbacks"] > 0                     # gloo rehearsal: the callback path (library RCCL would read 0)
+    assert c4["coherent_loop"]["equals_plain_run_bit_for_bit"] is True and c4["coherent_loop"]["ms_per_step"] > 0
     assert c5["cg_iters"] > 0 and c5["cg_iters_per_s"] > 0 and c5["err"] < c5["err0"] and 0 < c5["halo_fraction"] < 1
     assert c5["owned_vertices"] == 1800 and c5["collectives_per_cg_iteration"] == 3
 
