@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256) void occupancy_kernel(const double *__restrict
 
 template <int DIM>
 __global__ __launch_bounds__(GB) void cell_count_kernel(const double *__restrict__ tgt, int64_t m, GridParams gp,
-                                                       uint32_t *__restrict__ code_out, uint32_t *__restrict__ count) {
+                                                       uint32_t *__restrict__ code_out, uint32_t *__restrict__ count,
+                                                       uint32_t *__restrict__ rank_out) {
     const int64_t i = (int64_t)blockIdx.x * GB + threadIdx.x;
     if (i >= m) return;
     double p[DIM];
@@ -304,7 +305,10 @@ __global__ __launch_bounds__(GB) void cell_count_kernel(const double *__restrict
     cell_of<DIM>(p, gp, c);
     const uint32_t code = morton<DIM>(c);
     code_out[i] = code;
-    atomicAdd(&count[code], 1u);
+    // rank_out (unordered fill): the point's arrival number in its cell is its slot there -- the fill then needs no second
+    // round of atomics
+    if (rank_out) rank_out[i] = atomicAdd(&count[code], 1u);
+    else atomicAdd(&count[code], 1u);
 }
 
 // the cell codes alone (a build that only wants the Morton ORDER of its points: no cell ranges, no counters)
@@ -457,14 +461,14 @@ __global__ __launch_bounds__(GB) void gather_order_kernel(const double *__restri
 // (icp_rigid_run's reductions, icp_morton_sort) comes from the stable sort above.  1 M points: 45 us against
 // 160 (sort) + 43 (gather).
 template <int DIM>
-__global__ __launch_bounds__(GB) void scatter_atomic_kernel(const double *__restrict__ tgt, uint32_t *code, uint32_t *__restrict__ count,
+__global__ __launch_bounds__(GB) void scatter_atomic_kernel(const double *__restrict__ tgt, uint32_t *code, const uint32_t *__restrict__ rank,
                                                            const uint32_t *__restrict__ start, int64_t m,
                                                            double *__restrict__ spts, int32_t *__restrict__ sidx,
                                                            double4 *__restrict__ recs) {
     const int64_t i = (int64_t)blockIdx.x * GB + threadIdx.x;
     if (i >= m) return;
     const uint32_t c = code[i];
-    const uint32_t pos = start[c] + atomicSub(&count[c], 1u) - 1u;
+    const uint32_t pos = start[c] + rank[i];
     double4 rec;
     rec.x = tgt[i * DIM];
     rec.y = tgt[i * DIM + 1];
@@ -2124,16 +2128,18 @@ int grid_build_finish(icp_ctx *ctx, const GridPending &pend, GridBuild &gb) {
     uint32_t *count = gb.start + (ncell + 64);   // (256-byte aligned: the memset below is then one fill kernel, not three)
     uint32_t *bsum = (uint32_t *)sd.ptr;
     const unsigned mb = (unsigned)((m + GB - 1) / GB);
+    static const bool force_stable = getenv("ICP_GRID_STABLE") && atoi(getenv("ICP_GRID_STABLE")) != 0;
+    const bool sorted_fill = force_stable || m > ((int64_t)1 << 22);
+    uint32_t *rank = sorted_fill ? nullptr : codes + m;   // (the sort's scratch, unused by the unordered fill)
     ICP_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(uint32_t), st));
-    if (dim == 3) hipLaunchKernelGGL(cell_count_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, m, gp, codes, count);
-    else hipLaunchKernelGGL(cell_count_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, m, gp, codes, count);
+    if (dim == 3) hipLaunchKernelGGL(cell_count_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, m, gp, codes, count, rank);
+    else hipLaunchKernelGGL(cell_count_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, m, gp, codes, count, rank);
     hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nsb), dim3(GB), 0, st, (const uint32_t *)count, gb.start, bsum, ncell);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, bsum, (int)nsb);
     hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nsb), dim3(GB), 0, st, gb.start, (const uint32_t *)bsum, ncell, (uint32_t)m);
-    static const bool force_stable = getenv("ICP_GRID_STABLE") && atoi(getenv("ICP_GRID_STABLE")) != 0;
     // (beyond a few million points the scattered 56-byte writes of the unordered fill cost more than sort + gather:
     //  2^24 points 1.76 ms against 0.25 + 0.83; 2^20 points 68 us against 160 + 43)
-    if (force_stable || m > ((int64_t)1 << 22)) {
+    if (sorted_fill) {
         // (a sorted source and a large target are built on two streams at once by icp_rigid_run: separate sort storage)
         if (int rc = stable_sort_codes(ctx, ctx->sort_tmp_tgt, codes, codes + m, (int32_t *)(codes + 2 * m),
                                        gb.sidx, m, dim * bits))
@@ -2141,8 +2147,8 @@ int grid_build_finish(icp_ctx *ctx, const GridPending &pend, GridBuild &gb) {
         if (dim == 3) hipLaunchKernelGGL(scatter_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, gb.spts, (const int32_t *)gb.sidx, (double4 *)gb.recs);
         else hipLaunchKernelGGL(scatter_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, gb.spts, (const int32_t *)gb.sidx, (double4 *)gb.recs);
     } else {
-        if (dim == 3) hipLaunchKernelGGL(scatter_atomic_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, codes, count, (const uint32_t *)gb.start, m, gb.spts, gb.sidx, (double4 *)gb.recs);
-        else hipLaunchKernelGGL(scatter_atomic_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, codes, count, (const uint32_t *)gb.start, m, gb.spts, gb.sidx, (double4 *)gb.recs);
+        if (dim == 3) hipLaunchKernelGGL(scatter_atomic_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, codes, (const uint32_t *)rank, (const uint32_t *)gb.start, m, gb.spts, gb.sidx, (double4 *)gb.recs);
+        else hipLaunchKernelGGL(scatter_atomic_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, codes, (const uint32_t *)rank, (const uint32_t *)gb.start, m, gb.spts, gb.sidx, (double4 *)gb.recs);
     }
     ICP_HIP_CHECK(hipGetLastError());
     gb.gp = gp;
