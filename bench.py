@@ -320,12 +320,35 @@ def main():
     K, W = args.steps, args.warmup
     src_d, tgt_d = ctx.to_dev(src[lo:hi]), ctx.to_dev(tgt)
     n_loc = src_d.shape[0]
-    use_lib_rccl = args.comm == "rccl" and not args.share_gpu
+    # (ICP_BENCH_FORCE_LIBRCCL=1: try the library communicator even with ranks sharing a GPU -- RCCL refuses that, which is how
+    #  the fallback below is rehearsed on a one-GPU box)
+    use_lib_rccl = args.comm == "rccl" and (not args.share_gpu or os.environ.get("ICP_BENCH_FORCE_LIBRCCL") == "1")
     lib_rccl = None
     comm = None
+    rccl_note = None
     if distributed:
         if use_lib_rccl:
-            lib_rccl = _lib.LibraryRccl(ctx, rank=rank, world=world)       # the library's own communicator (id broadcast over torch)
+            # the library's own communicator (id broadcast over torch).  It has never run on more than one rank (no
+            # multi-GPU node in any round): if creating it, or a first tiny sharded run over it, fails on ANY rank, every
+            # rank falls back to the torch.distributed callbacks -- the headline must not depend on an unrehearsed path
+            ok, why = 1.0, ""
+            try:
+                lib_rccl = _lib.LibraryRccl(ctx, rank=rank, world=world)
+                tiny = ctx.to_dev(src[lo:hi][:4096])
+                rigid_icp_dist(tiny, ctx.to_dev(tgt[:8192]), 0.0, 2, use_tol=False, comm=RigidComm("cuda:%d" % local_rank, rccl=lib_rccl), ctx=ctx)
+                torch.cuda.synchronize()
+            except Exception as e:  # pragma: no cover (needs a multi-GPU node)
+                ok, why = 0.0, repr(e)
+            flag = torch.tensor([ok], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.cpu()[0]) != 1.0:
+                rccl_note = "library RCCL unavailable on this node (%s): torch.distributed callbacks instead" % (why or "another rank failed")
+                try:
+                    if lib_rccl is not None:
+                        lib_rccl.close()
+                except Exception:
+                    pass
+                lib_rccl = None
         comm = RigidComm("cuda:%d" % local_rank, rccl=lib_rccl)
     if args.rehearse_comm and not distributed:
         if use_lib_rccl:
@@ -532,7 +555,7 @@ def main():
                "check_idx_equal_bruteforce": None if check is None else check["idx_equal_bruteforce"],
                "n_checked": None if check is None else check["n_checked"],
                "collectives": ("library RCCL (icp_rccl_create): zero host callbacks" if lib_rccl is not None else
-                               ("host callback over torch.distributed" if comm is not None else "none (one rank)"))}
+                               ((rccl_note or "host callback over torch.distributed") if comm is not None else "none (one rank)"))}
         out = {
             "metric": "closest-point queries/s over full ICP iterations (Match+FindTransform+apply+Distance), %s pts" % (
                 "1Mx1M" if n == (1 << 20) else "%dx%d" % (n, n)),
