@@ -421,10 +421,32 @@ __global__ __launch_bounds__(GB) void scan_add_kernel(uint32_t *__restrict__ out
 // search may look at -- and, at the very end of the array, these copies (same index, same distance: never preferred).
 constexpr int kRecPad = 7;
 
+// fp32 PRE-FILTER of the per-lane search.  Beside its 32-byte record every target has a 16-byte one: its
+// coordinates in cell units, u = (x - mn) * inv_h, rounded to float.  The record walk forms the squared distance of those
+// to the query's in fp32 (half the bytes through the L1 path, a third of the vector-ALU cycles) and looks at the fp64 record
+// only when that cannot prove the fp64 d2 larger than what it is tested against.  The proof: for |u| <= 1.5 * 2^bits
+// (kFilterLo / kFilterHi below; anything else is stored as NaN, which never proves anything) each float coordinate is
+// within e1 = 2^-24 * 1.5 * 2^bits of the exact one, so with N the norm of the fp32 differences the true distance in cell
+// units is at least N (1 - 2^-24) - 2 sqrt(3) e1, the computed fp32 sum of squares is at most N^2 (1 + 2^-22), and the
+// computed fp64 d2 is at least the true one times (1 - 1e-15): a candidate with
+//     d2_f32 > [(sqrt(P) * inv_h + 2 sqrt(3) e1 * 1.001) * (1 + 1e-6)]^2      (rounded up to float)
+// has a computed fp64 d2 > P and can neither win nor tie against P (the best d2, or the second best in the BND forms).
+// Records in the padding are copies of the last one, as in the fp64 array.
+constexpr double kFilterLo = -0.5, kFilterHi = 1.5;   // in units of 2^bits cells
+template <int DIM>
+__device__ __forceinline__ float4 filter_record(double x, double y, double z, const GridParams &gp) {
+    const double nc = (double)(1 << gp.bits), lo = kFilterLo * nc, hi = kFilterHi * nc;
+    const double u0 = (x - gp.mn[0]) * gp.inv_h, u1 = (y - gp.mn[1]) * gp.inv_h, u2 = DIM == 3 ? (z - gp.mn[2]) * gp.inv_h : 0.0;
+    const bool safe = u0 >= lo && u0 <= hi && u1 >= lo && u1 <= hi && u2 >= lo && u2 <= hi;   // (NaN / inf: false)
+    return make_float4(safe ? (float)u0 : __builtin_nanf(""), (float)u1, (float)u2, 0.0f);
+}
+__device__ __forceinline__ float4 *filter_records(double4 *recs, int64_t m) { return (float4 *)(recs + m + kRecPad); }
+__device__ __forceinline__ const float4 *filter_records(const double4 *recs, int64_t m) { return (const float4 *)(recs + m + kRecPad); }
+
 template <int DIM>
 __global__ __launch_bounds__(GB) void scatter_kernel(const double *__restrict__ tgt, uint32_t *code,
                                                     int64_t m, double *__restrict__ spts, const int32_t *__restrict__ sidx,
-                                                    double4 *__restrict__ recs) {
+                                                    double4 *__restrict__ recs, GridParams gp) {
     const int64_t pos = (int64_t)blockIdx.x * GB + threadIdx.x;
     if (pos >= m) return;
     const int64_t i = sidx[pos];
@@ -436,8 +458,14 @@ __global__ __launch_bounds__(GB) void scatter_kernel(const double *__restrict__ 
     rec.z = DIM == 3 ? tgt[i * DIM + 2] : 0.0;
     rec.w = __longlong_as_double((long long)i);
     recs[pos] = rec;
+    const float4 frec = filter_record<DIM>(rec.x, rec.y, rec.z, gp);
+    float4 *recs32 = filter_records(recs, m);
+    recs32[pos] = frec;
     if (pos == m - 1)   // kRecPad copies of the last record: the searches read whole groups of records past a range's end
-        for (int k = 1; k <= kRecPad; ++k) recs[pos + k] = rec;
+        for (int k = 1; k <= kRecPad; ++k) {
+            recs[pos + k] = rec;
+            recs32[pos + k] = frec;
+        }
 #pragma unroll
     for (int a = 0; a < DIM; ++a) spts[(int64_t)pos * DIM + a] = tgt[i * DIM + a];
     code[i] = (uint32_t)pos;  // the cell code is spent: the array becomes the inverse permutation (GridBuild::inv)
@@ -464,7 +492,7 @@ template <int DIM>
 __global__ __launch_bounds__(GB) void scatter_atomic_kernel(const double *__restrict__ tgt, uint32_t *code, const uint32_t *__restrict__ rank,
                                                            const uint32_t *__restrict__ start, int64_t m,
                                                            double *__restrict__ spts, int32_t *__restrict__ sidx,
-                                                           double4 *__restrict__ recs) {
+                                                           double4 *__restrict__ recs, GridParams gp) {
     const int64_t i = (int64_t)blockIdx.x * GB + threadIdx.x;
     if (i >= m) return;
     const uint32_t c = code[i];
@@ -475,8 +503,14 @@ __global__ __launch_bounds__(GB) void scatter_atomic_kernel(const double *__rest
     rec.z = DIM == 3 ? tgt[i * DIM + 2] : 0.0;
     rec.w = __longlong_as_double((long long)i);
     recs[pos] = rec;
+    const float4 frec = filter_record<DIM>(rec.x, rec.y, rec.z, gp);
+    float4 *recs32 = filter_records(recs, m);
+    recs32[pos] = frec;
     if ((int64_t)pos == m - 1)
-        for (int k = 1; k <= kRecPad; ++k) recs[pos + k] = rec;
+        for (int k = 1; k <= kRecPad; ++k) {
+            recs[pos + k] = rec;
+            recs32[pos + k] = frec;
+        }
     spts[(int64_t)pos * DIM] = rec.x;
     spts[(int64_t)pos * DIM + 1] = rec.y;
     if (DIM == 3) spts[(int64_t)pos * DIM + 2] = rec.z;
@@ -742,15 +776,65 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             bp = pos;
         }
     };
-    auto scan = [&](uint32_t p0, uint32_t p1) {
-        for (uint32_t p = p0; p < p1; p += SCANN) {
+    // fp32 pre-filter (filter_record above): the query in cell units, the threshold the fp32 d2 is tested against, and the
+    // position of the best record so far (meeting it again changes nothing: skipped without its fp64 record)
+    constexpr bool FILT = !LE;
+    const float4 *recs32 = filter_records(recs, (int64_t)m);
+    float uq[3] = {0.0f, 0.0f, 0.0f};
+    bool f_ok = FILT && gp.h > 1e-100 && gp.h < 1e100;   // (far from the under- and overflow range: the relative error bounds hold)
+    if (FILT) {
+        const double nc = (double)(1 << gp.bits);
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) {
+            const double u = (s[a] - gp.mn[a]) * gp.inv_h;
+            f_ok = f_ok && u >= kFilterLo * nc && u <= kFilterHi * nc;
+            uq[a] = (float)u;
+        }
+    }
+    const double f_eps = 3.4641016151377544 * 1.001 * (0x1p-24 * kFilterHi * (1.0 + 1e-7)) * (double)(1 << gp.bits);
+    float f_thr = __builtin_inff();
+    uint32_t f_skip = 0xffffffffu;
+    auto refresh = [&]() {   // after every change of best / second
+        const double r = (__dsqrt_rn(ICP_PRUNE_AT) * gp.inv_h + f_eps) * (1.0 + 1e-6);
+        f_thr = f_ok ? __double2float_ru(r * r) : __builtin_inff();
+        f_skip = bi == 0x7fffffff ? 0xffffffffu : bp;
+    };
+    // SCANN records from position p on: the fp32 test for all of them, the fp64 records of those it cannot reject
+    auto walk = [&](uint32_t p) {
+        if (FILT) {
+            float4 rf[SCANN];
+            const float4 *b32 = recs32 + p;   // no clamp at the range's end: see kRecPad
+#pragma unroll
+            for (int u = 0; u < SCANN; ++u) rf[u] = b32[u];
+            bool pass[SCANN], any = false;
+#pragma unroll
+            for (int u = 0; u < SCANN; ++u) {
+                const float dx = rf[u].x - uq[0], dy = rf[u].y - uq[1];
+                float d = __builtin_fmaf(dy, dy, dx * dx);   // (fused: fewer roundings than the bound allows for)
+                if (DIM == 3) {
+                    const float dz = rf[u].z - uq[2];
+                    d = __builtin_fmaf(dz, dz, d);
+                }
+                pass[u] = !(d > f_thr) && p + (uint32_t)u != f_skip;   // (NaN: not rejected)
+                any = any || pass[u];
+            }
+            if (any) {
+#pragma unroll
+                for (int u = 0; u < SCANN; ++u)
+                    if (pass[u]) eval(recs[p + u], p + u);
+                refresh();
+            }
+        } else {
             double4 rc[SCANN];
-            const double4 *base = recs + p;   // no clamp at p1: see kRecPad
+            const double4 *base = recs + p;   // no clamp at the range's end: see kRecPad
 #pragma unroll
             for (int u = 0; u < SCANN; ++u) rc[u] = base[u];
 #pragma unroll
             for (int u = 0; u < SCANN; ++u) eval(rc[u], p + u);
         }
+    };
+    auto scan = [&](uint32_t p0, uint32_t p1) {
+        for (uint32_t p = p0; p < p1; p += SCANN) walk(p);
     };
 
     // ICP_HINT_IDX: a target the caller already knows (last iteration's match) is an ordinary candidate,
@@ -764,6 +848,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             eval(recs[hp], hp);
         }
     }
+    if (FILT) refresh();
     bool may_defer = true;
     for (int l = 0; l <= gp.bits; ++l) {
         if (l >= cap && may_defer) {
@@ -893,13 +978,8 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 const bool work = p < pe;
                 if (__builtin_amdgcn_ballot_w64(work) == 0) break;
                 if (work) {
-                    double4 rc[UNR];
                     static_assert(UNR - 1 <= kRecPad, "records read past the end of the array");
-                    const double4 *base = recs + p;   // no clamp at pe: see kRecPad
-#pragma unroll
-                    for (int u = 0; u < UNR; ++u) rc[u] = base[u];
-#pragma unroll
-                    for (int u = 0; u < UNR; ++u) eval(rc[u], p + u);
+                    walk(p);
                     p += UNR;
                     dbg_cand += UNR;
                 }
@@ -2116,7 +2196,7 @@ int grid_build_finish(icp_ctx *ctx, const GridPending &pend, GridBuild &gb) {
         gb.usable = true;
         return ICP_OK;
     }
-    if (int rc = ensure(ctx, sa, (size_t)m * (dim + 4) * sizeof(double) + 64 + kRecPad * 32)) return rc;   // sorted points | 32-byte records (+ pad)
+    if (int rc = ensure(ctx, sa, (size_t)m * (dim + 4) * sizeof(double) + 64 + kRecPad * 32 + (size_t)(m + kRecPad) * 16)) return rc;   // sorted points | 32-byte records (+ pad) | 16-byte filter records (+ pad)
     if (int rc = ensure(ctx, sb, (size_t)m * sizeof(int32_t) * 4)) return rc;     // sorted idx | codes | sorted codes | 0..m-1
     if (int rc = ensure(ctx, sc, (size_t)(ncell + 64) * sizeof(uint32_t) * 2)) return rc;  // start | count/fill
     if (int rc = ensure(ctx, sd, (size_t)(nsb + 1) * sizeof(uint32_t))) return rc;
@@ -2144,11 +2224,11 @@ int grid_build_finish(icp_ctx *ctx, const GridPending &pend, GridBuild &gb) {
         if (int rc = stable_sort_codes(ctx, ctx->sort_tmp_tgt, codes, codes + m, (int32_t *)(codes + 2 * m),
                                        gb.sidx, m, dim * bits))
             return rc;
-        if (dim == 3) hipLaunchKernelGGL(scatter_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, gb.spts, (const int32_t *)gb.sidx, (double4 *)gb.recs);
-        else hipLaunchKernelGGL(scatter_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, gb.spts, (const int32_t *)gb.sidx, (double4 *)gb.recs);
+        if (dim == 3) hipLaunchKernelGGL(scatter_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, gb.spts, (const int32_t *)gb.sidx, (double4 *)gb.recs, gp);
+        else hipLaunchKernelGGL(scatter_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, codes, m, gb.spts, (const int32_t *)gb.sidx, (double4 *)gb.recs, gp);
     } else {
-        if (dim == 3) hipLaunchKernelGGL(scatter_atomic_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, codes, (const uint32_t *)rank, (const uint32_t *)gb.start, m, gb.spts, gb.sidx, (double4 *)gb.recs);
-        else hipLaunchKernelGGL(scatter_atomic_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, codes, (const uint32_t *)rank, (const uint32_t *)gb.start, m, gb.spts, gb.sidx, (double4 *)gb.recs);
+        if (dim == 3) hipLaunchKernelGGL(scatter_atomic_kernel<3>, dim3(mb), dim3(GB), 0, st, tgt, codes, (const uint32_t *)rank, (const uint32_t *)gb.start, m, gb.spts, gb.sidx, (double4 *)gb.recs, gp);
+        else hipLaunchKernelGGL(scatter_atomic_kernel<2>, dim3(mb), dim3(GB), 0, st, tgt, codes, (const uint32_t *)rank, (const uint32_t *)gb.start, m, gb.spts, gb.sidx, (double4 *)gb.recs, gp);
     }
     ICP_HIP_CHECK(hipGetLastError());
     gb.gp = gp;

@@ -1,0 +1,15 @@
+# quick look at the per-lane search kernel: kernel trace + the SQ and TA counter groups (one run each)
+set -e
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+B="$R/bench.py --steps 10 --warmup 2 --no-cpu --no-nicp --no-check --repeats 0"
+O=$R/gpurun_out/quickprof
+rm -rf $O && mkdir -p $O
+timeout -s KILL 120 rocprofv3 --kernel-trace --stats -d $O/trace -o g -- python3 $B > $O/bench.json 2>/dev/null
+timeout -s KILL 90 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq -o p -- python3 $B > /dev/null 2>&1
+timeout -s KILL 90 rocprofv3 --pmc TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/ta -o p -- python3 $B > /dev/null 2>&1
+timeout -s KILL 90 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --kernel-trace --output-format csv -d $O/tcc -o p -- python3 $B > /dev/null 2>&1
+cd $R
+python3 profiles/summarize_rocpd.py $(find $O/trace -name "*.db" | head -1) gpurun_out/quick_kernel_stats.txt > /dev/null
+for d in sq ta tcc; do echo "== $d"; python3 profiles/pmc_summary.py $(find $O/$d -name "*counter_collection.csv" | head -1) grid_; done > gpurun_out/quick_pmc.txt
+head -12 gpurun_out/quick_kernel_stats.txt

@@ -55,6 +55,13 @@ def clouds():
     q[:200] *= 1e6
     q[200:400] = bulk[rng.integers(0, 60000, 200)] * (1 + 1e-9)
     out["far_outliers"] = (q, bulk)
+    # decisions far below float resolution (the per-lane pass rejects candidates on an fp32 distance in cell units and must
+    # pass on to the fp64 records whatever that cannot separate): every lattice point twice, 1e-10 apart, queries near the
+    # midpoints of cells and of edges, so that 2 - 16 targets are within 1e-9 (relative) of the minimum
+    g = np.stack(np.meshgrid(np.arange(24.), np.arange(24.), np.arange(24.), indexing="ij"), -1).reshape(-1, 3) * 0.37 + 100.0
+    tw = np.concatenate([g, g + rng.standard_normal(g.shape) * 1e-10])[rng.permutation(2 * len(g))]
+    qm = np.concatenate([g[:5000] + 0.185, g[:5000] + [0.185, 0, 0], g[:3000]]) + rng.standard_normal((13000, 3)) * 1e-10
+    out["below_float_resolution"] = (qm, tw)
     # heavy tails: a Cauchy cloud has no meaningful bounding box at all
     out["cauchy2"] = (rng.standard_cauchy((15000, 2)), rng.standard_cauchy((50000, 2)))
     return out
