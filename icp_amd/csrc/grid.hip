@@ -155,6 +155,18 @@ __device__ __forceinline__ void open_sides(const GridParams &gp, int a, int x, i
     if (x >= ncl - 1 && ((gp.open >> (2 * a + 1)) & 1)) gh = -__builtin_inf();
 }
 
+// inclusive prefix sum over the 64 lanes of a wave by DPP moves (rows of 16: shifts by 1, 2, 4, 8; then the last lane of a
+// row, and lane 31, broadcast to the rows behind them); six dependent vector instructions, no LDS round trips
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // LDS written by some lanes of a wave and read by others of the same wave: the hardware keeps a wave's LDS operations
 // in order, this keeps the compiler from moving them across each other
 __device__ __forceinline__ void lds_wave_sync() {
@@ -1027,6 +1039,446 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if (d2_out) d2_out[q] = best;
 }
 
+// The per-lane pass with the neighbour cells handled by the WAVE (argmin searches).  In
+// grid_query_kernel every lane looks up and walks its own surviving neighbour cells, so a wave takes as long as its
+// unluckiest lane -- the one with the most cells or records (2^20 x 2^20: 68 records for the longest lane of a wave
+// against 21 on average) -- and five sixths of the kernel's vector instructions were that phase.  Here the surviving cells of
+// all 64 queries go into ONE list per wave (a static pass over the 26 neighbours writes (cell code, owner lane) pairs at
+// slots from a wave-wide scan), and the wave works the list off 64 cells at a time: lane j looks up the range of cell j
+// and tests its records against the OWNER's query, which it reads from LDS (cell units, fp32: the pre-filter above).
+// A record the filter cannot reject is evaluated in fp64 by the lane that found it, with the owner's coordinates and
+// eval()'s arithmetic, and merged into the owner's slot by LDS atomics in three steps: least d2 (as bits: d2 >= 0), least
+// index among the records with that d2, position of that record -- the (d2, index) order of the full scan whatever the
+// order of arrival.  The owner then renews its threshold.  Lanes whose own query is finished, deferred or out of range keep
+// serving the others.  Own cell, hint, levels, gap test and hand-over to the deferred pass are those of grid_query_kernel.
+constexpr int kPoolCap = 384;   // list entries per wave and compaction pass (more: another pass)
+
+template <int DIM, bool FUSED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void grid_pool_kernel(
+    const double *__restrict__ src, int64_t n, const int32_t *__restrict__ qorder, const double4 *__restrict__ recs,
+    const uint32_t *__restrict__ start, GridParams gp, int32_t *idx_out, double *__restrict__ d2_out,
+    const int32_t *__restrict__ done, int cap, Deferred *__restrict__ deferred, uint32_t *__restrict__ n_deferred,
+    const int32_t *hint, const uint32_t *__restrict__ inv, uint32_t m, int pos_mode, int xcd_chunk,
+    const double *__restrict__ Rm, const double *__restrict__ tv, double *__restrict__ err_part, uint32_t defer_max) {
+    if (done && *done) return;
+    constexpr int QB = 256, NW = QB / 64, UNR = 3;
+#ifndef ICP_POOL_UNR
+#define ICP_POOL_UNR 3
+#endif
+    constexpr int PUNR = ICP_POOL_UNR;   // records per lane and trip of the wave-level walk
+    int64_t blk = blockIdx.x;
+    if (xcd_chunk > 0) {   // XCD-aware block order: see grid_query_kernel
+        const uint32_t per = 8u * (uint32_t)xcd_chunk, sc = blockIdx.x / per, r = blockIdx.x - sc * per;
+        blk = (int64_t)sc * per + (int64_t)(r & 7u) * xcd_chunk + (r >> 3);
+    }
+    const int64_t t = blk * QB + threadIdx.x;
+    const bool in_range = t < n;     // every lane stays to the end: it serves the other queries of its wave
+    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t q = in_range ? (qorder ? (int64_t)qorder[t] : t) : 0;
+    double s[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) s[a] = src[q * DIM + a];
+    if (FUSED) {   // ss = src R + t, operation for operation as apply_err_kernel forms it
+        double o[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            double v = s[0] * Rm[c];
+#pragma unroll
+            for (int k = 1; k < DIM; ++k) v += s[k] * Rm[k * DIM + c];
+            o[c] = v + tv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) s[c] = o[c];
+    }
+    int c0[DIM];
+    cell_of<DIM>(s, gp, c0);
+    double slack_abs[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) slack_abs[a] = (fabs(gp.mn[a]) + fabs(gp.mx[a])) * 0x1p-48;
+    double best = __builtin_inf();
+    int32_t bi = 0x7fffffff;
+    uint32_t bp = 0;
+    bool finite = true, isnan = false;
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) {
+        finite = finite && fabs(s[a]) < __builtin_inf();
+        isnan = isnan || s[a] != s[a];
+    }
+    if (FUSED) {   // error term of the previous iteration and the block's sum of them: see grid_query_kernel
+        double e = 0.0;
+        if (in_range) {
+            const uint32_t h = (uint32_t)hint[q];
+            const double4 rc = recs[h < m ? h : 0u];
+            const double dx = rc.x - s[0], dy = rc.y - s[1];
+            double d = dx * dx + dy * dy;
+            if (DIM == 3) {
+                const double dz = rc.z - s[2];
+                d = d + dz * dz;
+            }
+            e = sqrt(d);
+        }
+        __shared__ double ered[NW];
+        const double w = wave_sum(e);
+        if (ln == 0) ered[wv] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double v = ered[0];
+#pragma unroll
+            for (int k = 1; k < NW; ++k) v += ered[k];
+            err_part[blk] = v;
+        }
+    }
+    constexpr int NBR = DIM == 3 ? 27 : 9;
+    __shared__ uint2 plist[NW][kPoolCap];              // (cell code, owner lane), then (first record, owner lane)
+    __shared__ uint32_t ptab[NW][kPoolCap + 1];        // offset of the range's records in the wave's concatenation
+    __shared__ float4 pq[NW][64];                      // owner's query in cell units and its threshold
+    __shared__ uint32_t pskip[NW][64];                 // position of the owner's best record
+    __shared__ double psrc[NW][DIM][64];               // owner's query
+    __shared__ unsigned long long pbest[NW][64];       // owner's best d2 (bits)
+    __shared__ uint32_t pid[NW][64], ppos[NW][64];     // its index and position
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) psrc[wv][a][ln] = s[a];
+    lds_wave_sync();
+    bool active = in_range && finite, deferred_q = false;
+    if (in_range && !finite) {   // np.argmin of a constant NaN / inf row: index 0
+        idx_out[q] = pos_mode ? (int32_t)inv[0] : 0;
+        if (d2_out) d2_out[q] = isnan ? __builtin_nan("") : __builtin_inf();
+    }
+    // fp32 pre-filter (filter_record): the query in cell units, its threshold, the position of its best record
+    const float4 *recs32 = filter_records(recs, (int64_t)m);
+    float uq[3] = {0.0f, 0.0f, 0.0f};
+    bool f_ok = gp.h > 1e-100 && gp.h < 1e100;
+    {
+        const double nc = (double)(1 << gp.bits);
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) {
+            const double u = (s[a] - gp.mn[a]) * gp.inv_h;
+            f_ok = f_ok && u >= kFilterLo * nc && u <= kFilterHi * nc;
+            uq[a] = (float)u;
+        }
+    }
+    const double f_eps = 3.4641016151377544 * 1.001 * (0x1p-24 * kFilterHi * (1.0 + 1e-7)) * (double)(1 << gp.bits);
+    float f_thr = __builtin_inff();
+    uint32_t f_skip = 0xffffffffu;
+    auto refresh = [&]() {
+        const double r = (__dsqrt_rn(best) * gp.inv_h + f_eps) * (1.0 + 1e-6);
+        f_thr = f_ok ? __double2float_ru(r * r) : __builtin_inff();
+        f_skip = bi == 0x7fffffff ? 0xffffffffu : bp;
+    };
+    auto eval = [&](const double4 &rc, uint32_t pos) {
+        const double dx = rc.x - psrc[wv][0][ln], dy = rc.y - psrc[wv][1][ln];
+        double d = dx * dx + dy * dy;
+        if (DIM == 3) {
+            const double dz = rc.z - psrc[wv][2][ln];
+            d = d + dz * dz;
+        }
+        const int32_t id = (int32_t)__double_as_longlong(rc.w);
+        if (d < best || (d == best && id < bi)) {
+            best = d;
+            bi = id;
+            bp = pos;
+        }
+    };
+    auto own_scan = [&](uint32_t p0, uint32_t p1) {   // the query's own cell: per lane, as in grid_query_kernel
+        for (uint32_t p = p0; p < p1; p += UNR) {
+            float4 rf[UNR];
+            const float4 *b32 = recs32 + p;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) rf[u] = b32[u];
+            bool pass[UNR], any = false;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const float dx = rf[u].x - uq[0], dy = rf[u].y - uq[1];
+                float d = __builtin_fmaf(dy, dy, dx * dx);
+                if (DIM == 3) {
+                    const float dz = rf[u].z - uq[2];
+                    d = __builtin_fmaf(dz, dz, d);
+                }
+                pass[u] = !(d > f_thr) && p + (uint32_t)u != f_skip;
+                any = any || pass[u];
+            }
+            if (any) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    if (pass[u]) eval(recs[p + u], p + u);
+                refresh();
+            }
+        }
+    };
+    if (active && hint) {
+        const uint32_t h = (uint32_t)hint[q];
+        if (h < m) {
+            const uint32_t hp = pos_mode ? h : inv[h];
+            eval(recs[hp], hp);
+        }
+    }
+    refresh();
+
+    bool may_defer = true;
+    for (int l = 0; l <= gp.bits; ++l) {
+        if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+        if (active && l >= cap && may_defer) {   // hand-over to grid_defer_kernel: see grid_query_kernel
+            const uint32_t slot = atomicAdd(n_deferred, 1u);
+            may_defer = slot < defer_max;
+            if (may_defer) {
+                Deferred dq;
+                dq.q = (int32_t)q;
+                dq.level = l;
+                dq.bi = bi;
+                dq.bp = bp;
+                dq.best = best;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) dq.s[a] = a < DIM ? psrc[wv][a < DIM ? a : 0][ln] : 0.0;
+                dq.second = __builtin_inf();
+                deferred[slot] = dq;
+                active = false;
+                deferred_q = true;
+            }
+        }
+        const double hl = gp.h * (double)(1 << l);
+        const int ncl = 1 << (gp.bits - l);
+        const double slack_h = hl * 0x1p-20;
+        int cl[DIM];
+        float g2[DIM][3];   // squared gaps as floats scaled by (1 - 2^-21): their rounded sum stays below the fp64 bound
+        bool okc[DIM][3];
+        uint32_t sp[DIM][3];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) {
+            cl[a] = c0[a] >> l;
+            const double sl = slack_h + slack_abs[a];
+            const double sa = psrc[wv][a][ln];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const int x = cl[a] + o - 1;
+                okc[a][o] = x >= 0 && x < ncl;
+                sp[a][o] = okc[a][o] ? (DIM == 3 ? spread3((uint32_t)x) : spread2((uint32_t)x)) << a : 0u;
+                const double lo = gp.mn[a] + (double)x * hl, hi = gp.mn[a] + (double)(x + 1) * hl;
+                double g = lo - sa - sl;
+                double gh = sa - hi - sl;
+                open_sides(gp, a, x, ncl, g, gh);
+                g = gh > g ? gh : g;
+                g = g > 0.0 ? g : 0.0;
+                g2[a][o] = __double2float_rd(g * g) * (1.0f - 0x1p-21f);
+            }
+        }
+        if (active) {   // phase A: the query's own cell, per lane (in the list it costs more: its records improve most bests, one merge each)
+            uint32_t code = sp[0][1] | sp[1][1];
+            if (DIM == 3) code |= sp[2][1];
+            own_scan(start[(uint64_t)code << (DIM * l)], start[((uint64_t)code + 1) << (DIM * l)]);
+        }
+        // phase B: the neighbour cells that can still hold a better (or tying) point
+        uint32_t mask = 0;
+        if (active) {
+            const float bestf = __double2float_ru(best);
+#pragma unroll
+            for (int nb = 0; nb < NBR; ++nb) {
+                if (nb == NBR / 2) continue;
+                const int ox = nb % 3, oy = (nb / 3) % 3, oz = nb / 9;
+                bool inside = okc[0][ox] && okc[1][oy];
+                float bound = g2[0][ox] + g2[1][oy];
+                if (DIM == 3) {
+                    inside = inside && okc[2][oz];
+                    bound = bound + g2[2][oz];
+                }
+                if (inside && !(bound > bestf)) mask |= 1u << nb;
+            }
+        }
+        // what the other lanes need of this query
+        unsigned long long mybits = (unsigned long long)__double_as_longlong(best);
+        pq[wv][ln] = make_float4(uq[0], uq[1], uq[2], f_thr);
+        pskip[wv][ln] = f_skip;
+        pbest[wv][ln] = mybits;
+        pid[wv][ln] = (uint32_t)bi;
+        ppos[wv][ln] = bp;
+        // phase C: the wave's list of (cell, owner) pairs, worked off 64 at a time
+        while (true) {
+            const uint32_t cnt = (uint32_t)__builtin_popcount(mask);
+            const uint32_t inc = wave_scan_u32(cnt);
+            const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            if (T == 0) break;
+            lds_wave_sync();   // (the previous pass's list has been read)
+            uint32_t slot = inc - cnt;
+#pragma unroll
+            for (int nb = 0; nb < NBR; ++nb) {
+                const int ox = nb % 3, oy = (nb / 3) % 3, oz = nb / 9;
+                if (mask & (1u << nb)) {
+                    if (slot < (uint32_t)kPoolCap) {
+                        uint32_t code = sp[0][ox] | sp[1][oy];
+                        if (DIM == 3) code |= sp[2][oz];
+                        plist[wv][slot] = make_uint2(code, (uint32_t)ln);
+                        mask &= ~(1u << nb);
+                    }
+                    ++slot;
+                }
+            }
+            lds_wave_sync();
+            const uint32_t Tc = T < (uint32_t)kPoolCap ? T : (uint32_t)kPoolCap;
+            // every range of the list looked up at once (entries [ln K', ln K' + K') by lane ln), their lengths scanned into
+            // the offsets of ONE concatenation of all the records the wave has to test
+            constexpr int KMAX = kPoolCap / 64;
+            const uint32_t Kp = (Tc + 63u) / 64u;
+            uint32_t er0[KMAX], elen[KMAX], eown[KMAX], lsum = 0;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const uint32_t idx = (uint32_t)ln * Kp + (uint32_t)k;
+                const bool have = (uint32_t)k < Kp && idx < Tc;
+                const uint2 e = plist[wv][have ? idx : 0u];
+                uint32_t a0 = 0, a1 = 0;
+                if (have) {
+                    a0 = start[(uint64_t)e.x << (DIM * l)];
+                    a1 = start[((uint64_t)e.x + 1) << (DIM * l)];
+                }
+                er0[k] = a0;
+                elen[k] = a1 - a0;
+                eown[k] = e.y;
+            }
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) lsum += elen[k];
+            const uint32_t linc = wave_scan_u32(lsum);
+            const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)linc, 63);
+            {
+                uint32_t pre = linc - lsum;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    const uint32_t idx = (uint32_t)ln * Kp + (uint32_t)k;
+                    if ((uint32_t)k < Kp && idx < Tc) {
+                        plist[wv][idx] = make_uint2(er0[k], eown[k]);   // (the cell code is spent)
+                        ptab[wv][idx] = pre;
+                    }
+                    pre += elen[k];
+                }
+                if (ln == 0) ptab[wv][Tc] = R;
+            }
+            lds_wave_sync();
+            // lane ln tests records [ln C, ln C + C) of the concatenation, PUNR consecutive ones per trip
+            const uint32_t C = (R + 63u) / 64u;
+            uint32_t i0 = (uint32_t)ln * C;
+            const uint32_t iend = i0 + C < R ? i0 + C : R;
+            uint32_t cur = 0;
+            {
+                uint32_t hi = Tc;   // last entry whose offset is <= i0 (empty ranges share their offset with the next entry)
+                while (hi - cur > 1) {
+                    const uint32_t mid = (cur + hi) >> 1;
+                    if (ptab[wv][mid] <= i0) cur = mid;
+                    else hi = mid;
+                }
+            }
+            uint2 ce = plist[wv][cur];
+            uint32_t cpre = ptab[wv][cur], cnext = ptab[wv][cur + 1];
+            for (; __builtin_amdgcn_ballot_w64(i0 < iend) != 0; i0 += PUNR) {
+                bool pass[PUNR];
+                uint32_t pos[PUNR], own[PUNR];
+#pragma unroll
+                for (int u = 0; u < PUNR; ++u) {
+                    const uint32_t ii = i0 + (uint32_t)u;
+                    pass[u] = ii < iend;
+                    while (pass[u] && ii >= cnext) {   // (entries behind the last one do not exist: ii < R = the sentinel)
+                        ++cur;
+                        ce = plist[wv][cur];
+                        cpre = cnext;
+                        cnext = ptab[wv][cur + 1];
+                    }
+                    pos[u] = pass[u] ? ce.x + (ii - cpre) : 0u;
+                    own[u] = ce.y;
+                }
+                float4 rf[PUNR];
+#pragma unroll
+                for (int u = 0; u < PUNR; ++u) rf[u] = recs32[pos[u]];
+#pragma unroll
+                for (int u = 0; u < PUNR; ++u) {
+                    const float4 oq = pq[wv][own[u]];
+                    const uint32_t osk = pskip[wv][own[u]];
+                    const float dx = rf[u].x - oq.x, dy = rf[u].y - oq.y;
+                    float d = __builtin_fmaf(dy, dy, dx * dx);
+                    if (DIM == 3) {
+                        const float dz = rf[u].z - oq.z;
+                        d = __builtin_fmaf(dz, dz, d);
+                    }
+                    pass[u] = pass[u] && !(d > oq.w) && pos[u] != osk;
+                }
+#pragma unroll
+                for (int u = 0; u < PUNR; ++u) {
+                    if (__builtin_amdgcn_ballot_w64(pass[u]) == 0) continue;
+                    // fp64 evaluation by the finder (a candidate that cannot reach the owner's present best is dropped at
+                    // once), then the merge into the owner's slot
+                    const int o = (int)own[u];
+                    unsigned long long db = ~0ull;
+                    uint32_t id = 0x7fffffffu;
+                    bool cand = false;
+                    if (pass[u]) {
+                        const double4 rc = recs[pos[u]];
+                        const double dx = rc.x - psrc[wv][0][o], dy = rc.y - psrc[wv][1][o];
+                        double d = dx * dx + dy * dy;
+                        if (DIM == 3) {
+                            const double dz = rc.z - psrc[wv][2][o];
+                            d = d + dz * dz;
+                        }
+                        id = (uint32_t)(int32_t)__double_as_longlong(rc.w);
+                        db = (unsigned long long)__double_as_longlong(d);
+                        cand = db <= pbest[wv][o];
+                    }
+                    if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
+                    if (cand) atomicMin(&pbest[wv][o], db);
+                    lds_wave_sync();
+                    const unsigned long long nbits = pbest[wv][ln];
+                    const bool chg = nbits != mybits;
+                    if (chg) {   // a better d2 for this lane's own query: its old index no longer counts
+                        pid[wv][ln] = 0x7fffffffu;
+                        mybits = nbits;
+                    }
+                    lds_wave_sync();
+                    const bool top = cand && db == pbest[wv][o];
+                    if (top) atomicMin(&pid[wv][o], id);
+                    lds_wave_sync();
+                    if (top && id == pid[wv][o]) ppos[wv][o] = pos[u];
+                    lds_wave_sync();
+                    const uint32_t nid = pid[wv][ln];
+                    if (chg || nid != (uint32_t)bi) {
+                        best = __longlong_as_double((long long)mybits);
+                        bi = (int32_t)nid;
+                        bp = ppos[wv][ln];
+                        refresh();
+                        pq[wv][ln].w = f_thr;
+                        pskip[wv][ln] = f_skip;
+                    }
+                    lds_wave_sync();
+                }
+            }
+            if (T <= (uint32_t)kPoolCap) break;   // (every mask is empty: no second scan to find that out)
+        }
+        lds_wave_sync();   // (before the slots are rewritten at the next level)
+        if (active) {
+            if (ncl == 1) {
+                active = false;  // the neighbourhood was the whole grid
+            } else {
+                double mgap = __builtin_inf();
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) {
+                    const double sl = slack_h + slack_abs[a];
+                    const double sa = psrc[wv][a][ln];
+                    if (cl[a] - 1 > 0) {
+                        const double g = sa - (gp.mn[a] + (double)(cl[a] - 1) * hl) - sl;
+                        mgap = g < mgap ? g : mgap;
+                    }
+                    if (cl[a] + 2 < ncl) {
+                        const double g = (gp.mn[a] + (double)(cl[a] + 2) * hl) - sa - sl;
+                        mgap = g < mgap ? g : mgap;
+                    }
+                }
+                if (mgap == __builtin_inf()) active = false;  // box covers the grid
+                else if (mgap > 0.0 && best < mgap * mgap) active = false;
+            }
+        }
+    }
+    if (!in_range || !finite || deferred_q) return;
+    if (bi == 0x7fffffff) {  // nothing comparable found (e.g. every d2 = +inf): np.argmin -> 0
+        bi = 0;
+        bp = inv[0];
+    }
+    idx_out[q] = pos_mode ? (int32_t)bp : bi;
+    if (d2_out) d2_out[q] = best;
+}
+
 // Second pass: HALF a wave per deferred query.  Same search (3^DIM neighbourhood per level, bound test, gap test), but
 // the 27 range lookups are done by 27 lanes at once and the surviving ranges are scanned 32 records per step, so a
 // query that needs many levels costs a few microseconds.  The pass is a chain of dependent latencies per level (ranges ->
@@ -1088,7 +1540,7 @@ __global__ __launch_bounds__(64) void grid_defer_kernel(const double4 *__restric
     if (done && *done) return;
     constexpr int NBR = DIM == 3 ? 27 : 9;
     constexpr int G = ICP_DEFER_G;  // lanes per query
-    constexpr uint32_t GMASK = G == 32 ? 0xffffffffu : ((1u << G) - 1u);
+    constexpr uint32_t GMASK = (uint32_t)((1ull << G) - 1ull);
     __shared__ uint32_t stk[64 / G][kStack];
     const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
     const uint32_t nd = *n_deferred < defer_max ? *n_deferred : defer_max;   // (lanes that found the list full kept their queries)
@@ -2369,6 +2821,24 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
         if (list8) ICP_GQ2(D, L, F, 8, 4); \
         else ICP_GQ2(D, L, F, 4, 3); \
     } while (0)
+    // argmin searches: the neighbour cells worked off by the wave (grid_pool_kernel), then the same deferred pass
+#define ICP_GQP(D, F) \
+    do { \
+        if (g_grid_events) (void)hipEventRecord(g_grid_events[0], st); \
+        hipLaunchKernelGGL((grid_pool_kernel<D, F>), dim3(nb), dim3(256), 0, st, src, n, qorder, (const double4 *)gb.recs, \
+                           (const uint32_t *)gb.start, gb.gp, idx_out, d2_out, done, cap, dlist, ndef, hint, \
+                           (const uint32_t *)gb.inv, (uint32_t)gb.m, pos_mode ? 1 : 0, xcd_chunk, fR, ft, \
+                           fa ? (double *)ctx->err_part.ptr : (double *)nullptr, defer_max); \
+        if (g_grid_events) (void)hipEventRecord(g_grid_events[1], st); \
+        if (cap < 1000) \
+            hipLaunchKernelGGL((grid_defer_kernel<D, false, false>), dim3(nb2), dim3(64), 0, st, (const double4 *)gb.recs, \
+                               (const uint32_t *)gb.start, gb.gp, thr, idx_out, d2_out, done, (const Deferred *)dlist, \
+                               (const uint32_t *)ndef, ndef_next, (const uint32_t *)gb.inv, pos_mode ? 1 : 0, \
+                               jump_env >= 0 ? jump_env : ((hint && pos_mode) ? 1 : 0), split_env, clb, csr, defer_max); \
+        if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
+    } while (0)
+    static const int pool_env = getenv("ICP_GRID_POOL") ? atoi(getenv("ICP_GRID_POOL")) : 1;   // (0: per-lane kernel everywhere; 2: the pool kernel for unhinted searches too)
+    const bool pool = pool_env != 0 && (hint || pool_env > 1) && !le && !coh && !g_grid_dbg && !list8;
     static const bool coh_trace = getenv("ICP_COHERENT_TRACE") != nullptr;
     // share of unproven rows beyond which an iteration takes the whole-cloud search (ICP_COHERENT_LIMIT, default 0.12)
     static const double coh_frac = getenv("ICP_COHERENT_LIMIT") ? atof(getenv("ICP_COHERENT_LIMIT")) : 0.12;
@@ -2380,6 +2850,14 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
     } else if (coh) {   // first iteration: the bounded search for every query (the list-of-8 probe has no bounded variant)
         if (gb.gp.dim == 3) ICP_GQ3(3, false, false, 4, 3, true);
         else ICP_GQ3(2, false, false, 4, 3, true);
+    } else if (pool) {
+        if (gb.gp.dim == 3) {
+            if (fa) ICP_GQP(3, true);
+            else ICP_GQP(3, false);
+        } else {
+            if (fa) ICP_GQP(2, true);
+            else ICP_GQP(2, false);
+        }
     } else if (gb.gp.dim == 3) {
         if (le) ICP_GQL(3, true, false);
         else if (fa) ICP_GQL(3, false, true);
@@ -2390,6 +2868,7 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
         else ICP_GQL(2, false, false);
     }
 #undef ICP_GQL
+#undef ICP_GQP
 #undef ICP_GQ2
 #undef ICP_GQ3
 #undef ICP_GQC
