@@ -1051,7 +1051,10 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 // index among the records with that d2, position of that record -- the (d2, index) order of the full scan whatever the
 // order of arrival.  The owner then renews its threshold.  Lanes whose own query is finished, deferred or out of range keep
 // serving the others.  Own cell, hint, levels, gap test and hand-over to the deferred pass are those of grid_query_kernel.
-constexpr int kPoolCap = 384;   // list entries per wave and compaction pass (more: another pass)
+#ifndef ICP_POOL_CAP
+#define ICP_POOL_CAP 384
+#endif
+constexpr int kPoolCap = ICP_POOL_CAP;   // list entries per wave and compaction pass (more: another pass)
 
 template <int DIM, bool FUSED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void grid_pool_kernel(

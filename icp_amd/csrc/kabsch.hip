@@ -1092,7 +1092,7 @@ extern "C" int icp_bench_grid_query(icp_ctx *ctx, const double *src, int64_t n, 
     }
     if (int rc = grid_build(ctx, src, n, dim, qsort, 1)) return rc;
     const double *q = qsort.usable ? qsort.spts : src;
-    if (int rc = ensure(ctx, ctx->work_d, (size_t)n * sizeof(int32_t))) return rc;
+    if (int rc = ensure(ctx, ctx->work_d, (size_t)n * sizeof(int32_t) * 2)) return rc;
     int32_t *idx = (int32_t *)ctx->work_d.ptr;
     hipStream_t s = ctx->stream;
     if (int rc = grid_query(ctx, grid, q, n, nullptr, false, nullptr, idx, nullptr, nullptr)) return rc;  // warm
@@ -1140,7 +1140,41 @@ extern "C" int icp_bench_grid_query(icp_ctx *ctx, const double *src, int64_t n, 
             fclose(f);
         }
     }
-    const double avg[3] = {(double)ms / reps, ms_lane / reps, ms_defer / reps};
+    // the same search as iterations 2.. of the rigid loop run it: with the previous answer as the hint (grid_pool_kernel)
+    double ms_h = 0.0, ms_hlane = 0.0, ms_hdefer = 0.0;
+    {
+        int32_t *idx2 = idx + n;   // (correspondences as sorted positions, as the loop keeps them between iterations)
+        if (int rc = grid_query(ctx, grid, q, n, nullptr, false, nullptr, idx, nullptr, nullptr, nullptr, true)) return rc;
+        if (int rc = grid_query(ctx, grid, q, n, nullptr, false, nullptr, idx2, nullptr, nullptr, idx, true)) return rc;  // warm
+        hipEvent_t h0, h1;
+        ICP_HIP_CHECK(hipEventCreate(&h0));
+        ICP_HIP_CHECK(hipEventCreate(&h1));
+        ICP_HIP_CHECK(hipEventRecord(h0, s));
+        for (int r = 0; r < reps; ++r)
+            if (int rc = grid_query(ctx, grid, q, n, nullptr, false, nullptr, idx2, nullptr, nullptr, idx, true)) return rc;
+        ICP_HIP_CHECK(hipEventRecord(h1, s));
+        ICP_HIP_CHECK(hipEventSynchronize(h1));
+        float t = 0.f;
+        ICP_HIP_CHECK(hipEventElapsedTime(&t, h0, h1));
+        ms_h = t;
+        (void)hipEventDestroy(h0);
+        (void)hipEventDestroy(h1);
+        for (int k = 0; k < 3; ++k) ICP_HIP_CHECK(hipEventCreate(&ev[k]));
+        for (int r = 0; r < reps; ++r) {
+            g_grid_events = ev;
+            const int rc = grid_query(ctx, grid, q, n, nullptr, false, nullptr, idx2, nullptr, nullptr, idx, true);
+            g_grid_events = nullptr;
+            if (rc) return rc;
+            ICP_HIP_CHECK(hipEventSynchronize(ev[2]));
+            float a = 0.f, b2 = 0.f;
+            ICP_HIP_CHECK(hipEventElapsedTime(&a, ev[0], ev[1]));
+            ICP_HIP_CHECK(hipEventElapsedTime(&b2, ev[1], ev[2]));
+            ms_hlane += a;
+            ms_hdefer += b2;
+        }
+        for (int k = 0; k < 3; ++k) (void)hipEventDestroy(ev[k]);
+    }
+    const double avg[6] = {(double)ms / reps, ms_lane / reps, ms_defer / reps, ms_h / reps, ms_hlane / reps, ms_hdefer / reps};
     ICP_HIP_CHECK(hipMemcpyAsync(ms_out_dev, avg, sizeof(avg), hipMemcpyHostToDevice, s));
     ICP_HIP_CHECK(hipStreamSynchronize(s));
     return ICP_OK;

@@ -118,15 +118,18 @@ def rigid_icp(source, target, tol, run, use_tol=True, compare_sqrt=False, force_
     return out
 
 
-def time_grid_query(source, target, reps=5, ctx=None, parts=False):
+def time_grid_query(source, target, reps=5, ctx=None, parts=False, hinted=False):
     """Average duration (s) of one grid search as it runs inside icp_rigid_run: target grid
     prebuilt, queries in Morton order.  Measured with HIP events on the launch stream
-    (bench.py's roofline leg).  parts=True: (whole search, grid_query_kernel, grid_defer_kernel)."""
+    (bench.py's roofline leg).  parts=True: (whole search, per-lane kernel, grid_defer_kernel).
+    hinted=True: the search with the previous answer as its hint (iterations 2.. of a loop:
+    grid_pool_kernel); False: without (the first iteration: grid_query_kernel)."""
     ctx = ctx or get_context()
     torch = ctx.torch
     src, tgt, dim = _dims(ctx, source, target)
-    ms = ctx.empty((3,))
+    ms = ctx.empty((6,))
     ctx.call("icp_bench_grid_query", ptr(src), src.shape[0], ptr(tgt), tgt.shape[0], dim, int(reps), ptr(ms))
     torch.cuda.synchronize()
     t = [float(x) * 1e-3 for x in ms.cpu()]
+    t = t[3:] if hinted else t[:3]
     return tuple(t) if parts else t[0]

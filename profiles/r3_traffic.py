@@ -31,28 +31,30 @@ def main(root, stats):
         name, rest = ln[:110], ln[110:].split()
         dur[name.strip()] = float(rest[2]) * 1e-3          # average, microseconds
     pick = lambda frag: [k for k in c if frag in k]
-    nohint = [k for k in pick("grid_query_kernel") if "4, false, 4, 3>" in k][0]
-    loop = [k for k in pick("grid_query_kernel") if "4, true, 4, 3>" in k][0]
-    defer = pick("grid_defer_kernel")[0]
+    nohint = [k for k in pick("grid_query_kernel") if "4, false, 4, 3, false, 0>" in k][0]
+    loop = [k for k in pick("grid_pool_kernel") if "<3, true>" in k][0]
+    hinted = [k for k in pick("grid_pool_kernel") if "<3, false>" in k][0]     # what bench.py's roofline leg times
+    defer = [k for k in pick("grid_defer_kernel") if "false, false>" in k][0]
     us = lambda k: [v for n, v in dur.items() if k[:100].startswith(n[:100]) or n[:100].startswith(k[:100])][0]
     bytes_of = lambda k: 2.0 * c[k]["FETCH_SIZE"] * 1024 + c[k]["WRITE_SIZE"] * 1024
     cyc = us(loop) * 1e3 * CLOCK_GHZ
     out = {
-        "kernel": "grid search = grid_query_kernel + grid_defer_kernel (no hints: what bench.py's roofline leg times)",
+        "kernel": "grid search = grid_pool_kernel + grid_defer_kernel (previous answer as the hint: what bench.py's roofline leg times)",
         "workload": "2^20 x 2^20 (C2)",
-        "fetch_size_kb": {"grid_query_kernel": c[nohint]["FETCH_SIZE"], "grid_defer_kernel": c[defer]["FETCH_SIZE"]},
+        "fetch_size_kb": {"grid_pool_kernel": c[hinted]["FETCH_SIZE"], "grid_defer_kernel": c[defer]["FETCH_SIZE"]},
         "fetch_correction": 2.0,
-        "write_size_kb": {"grid_query_kernel": c[nohint]["WRITE_SIZE"], "grid_defer_kernel": c[defer]["WRITE_SIZE"]},
-        "traffic_bytes": bytes_of(nohint) + bytes_of(defer),
+        "write_size_kb": {"grid_pool_kernel": c[hinted]["WRITE_SIZE"], "grid_defer_kernel": c[defer]["WRITE_SIZE"]},
+        "traffic_bytes": bytes_of(hinted) + bytes_of(defer),
+        "first_iteration_no_hints": {"traffic_bytes": bytes_of(nohint) + bytes_of(defer), "kernel_us": us(nohint)},
         "in_loop_with_hints_fused": {"traffic_bytes": bytes_of(loop) + bytes_of(defer), "kernel_us": us(loop), "defer_us": us(defer)},
         "valu_busy": c[loop]["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cyc,
         "ta_busy": c[loop]["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / cyc,
         "ta_busy_counter": (c[loop]["TA_BUSY_avr"] / cyc) if "TA_BUSY_avr" in c[loop] else None,   # TA_BUSY_avr counts busy cycles
         "wait_frac": c[loop]["SQ_WAIT_ANY"] / c[loop]["SQ_WAVE_CYCLES"],
         "l2_hit": c[loop]["TCC_HIT_sum"] / (c[loop]["TCC_HIT_sum"] + c[loop]["TCC_MISS_sum"]),
-        "busy_note": "per-lane kernel inside the ICP loop: valu_busy = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / kernel cycles at 2.4 GHz; "
+        "busy_note": "grid_pool_kernel<3, true> inside the ICP loop: valu_busy = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / kernel cycles at 2.4 GHz; "
                      "ta_busy = L1 line accesses per compute unit / kernel cycles (one line per cycle); wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES",
-        "source": "profiles/r3_pmc_grid.txt (rocprofv3 --pmc, one counter group per run: profiles/run_r3_profiles.sh; gfx950 x2 correction for FETCH_SIZE)",
+        "source": "profiles/r3_pmc_grid_pool.txt (rocprofv3 --pmc, one counter group per run: profiles/run_r3_profiles.sh; gfx950 x2 correction for FETCH_SIZE)",
     }
     print(json.dumps(out))
 

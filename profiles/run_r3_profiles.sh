@@ -15,6 +15,6 @@ timeout -s KILL 90 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_IN
 timeout -s KILL 90 rocprofv3 --pmc TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/ta -o p -- python3 $B > /dev/null 2>&1
 cd $R
 python3 profiles/summarize_rocpd.py $(find $O/trace -name "*.db" | head -1) gpurun_out/r3_kernel_stats_grid.txt > /dev/null
-for d in fetch write tcc sq ta; do echo "== $d"; python3 profiles/pmc_summary.py $(find $O/$d -name "*counter_collection.csv" | head -1) grid_; done > gpurun_out/r3_pmc_grid_raw.txt
+for d in fetch write tcc sq ta; do echo "== $d"; python3 profiles/pmc_summary.py $(find $O/$d -name "*counter_collection.csv" | head -1) grid_; done > gpurun_out/r3_pmc_grid_pool_raw.txt
 python3 profiles/r3_traffic.py $O gpurun_out/r3_kernel_stats_grid.txt > gpurun_out/r3_traffic.json
 cat gpurun_out/r3_traffic.json
