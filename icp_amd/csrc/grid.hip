@@ -1044,8 +1044,9 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 // unluckiest lane -- the one with the most cells or records (2^20 x 2^20: 68 records for the longest lane of a wave
 // against 21 on average) -- and five sixths of the kernel's vector instructions were that phase.  Here the surviving cells of
 // all 64 queries go into ONE list per wave (a static pass over the 26 neighbours writes (cell code, owner lane) pairs at
-// slots from a wave-wide scan), and the wave works the list off 64 cells at a time: lane j looks up the range of cell j
-// and tests its records against the OWNER's query, which it reads from LDS (cell units, fp32: the pre-filter above).
+// slots from a wave-wide scan); all ranges of the list are looked up at once, their lengths are scanned into the offsets of
+// one concatenation of all the records the wave has to test, and every lane tests an equal share of it, consecutive records,
+// against the OWNER's query, which it reads from LDS (cell units, fp32: the pre-filter above).
 // A record the filter cannot reject is evaluated in fp64 by the lane that found it, with the owner's coordinates and
 // eval()'s arithmetic, and merged into the owner's slot by LDS atomics in three steps: least d2 (as bits: d2 >= 0), least
 // index among the records with that d2, position of that record -- the (d2, index) order of the full scan whatever the
@@ -1054,7 +1055,10 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 #ifndef ICP_POOL_CAP
 #define ICP_POOL_CAP 384
 #endif
-constexpr int kPoolCap = ICP_POOL_CAP;   // list entries per wave and compaction pass (more: another pass)
+constexpr int kPoolCap = ICP_POOL_CAP;   // list entries per wave and compaction pass (more: another pass; 256 / 384 / 512: 177 / 169 / 170 us)
+#ifndef ICP_POOL_UNR
+#define ICP_POOL_UNR 3                   // records per lane and trip of the wave-level walk (2 / 3 / 4 / 6: 169 / 169 / 169 / 185 us)
+#endif
 
 template <int DIM, bool FUSED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void grid_pool_kernel(
@@ -1064,11 +1068,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int32_t *hint, const uint32_t *__restrict__ inv, uint32_t m, int pos_mode, int xcd_chunk,
     const double *__restrict__ Rm, const double *__restrict__ tv, double *__restrict__ err_part, uint32_t defer_max) {
     if (done && *done) return;
-    constexpr int QB = 256, NW = QB / 64, UNR = 3;
-#ifndef ICP_POOL_UNR
-#define ICP_POOL_UNR 3
-#endif
-    constexpr int PUNR = ICP_POOL_UNR;   // records per lane and trip of the wave-level walk
+    constexpr int QB = 256, NW = QB / 64, UNR = 3, PUNR = ICP_POOL_UNR;
     int64_t blk = blockIdx.x;
     if (xcd_chunk > 0) {   // XCD-aware block order: see grid_query_kernel
         const uint32_t per = 8u * (uint32_t)xcd_chunk, sc = blockIdx.x / per, r = blockIdx.x - sc * per;
