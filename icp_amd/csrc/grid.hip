@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     constexpr int NBR = DIM == 3 ? 27 : 9;
     __shared__ uint2 plist[NW][kPoolCap];              // (cell code, owner lane), then (first record, owner lane)
-    __shared__ uint32_t ptab[NW][kPoolCap + 1];        // offset of the range's records in the wave's concatenation
+    __shared__ uint32_t ptab[NW][kPoolCap + 4];        // offset of the range's records in the wave's concatenation (+ sentinels)
     __shared__ float4 pq[NW][64];                      // owner's query in cell units and its threshold
     __shared__ uint32_t pskip[NW][64];                 // position of the owner's best record
     __shared__ double psrc[NW][DIM][64];               // owner's query
@@ -1339,65 +1339,88 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int k = 0; k < KMAX; ++k) lsum += elen[k];
             const uint32_t linc = wave_scan_u32(lsum);
             const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)linc, 63);
+            // the table keeps the NON-EMPTY ranges only (first record, owner; offset), so that PUNR consecutive records of the
+            // concatenation lie in at most PUNR consecutive entries and a trip finds them without a loop
+            uint32_t ne = 0;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) ne += elen[k] ? 1u : 0u;
+            const uint32_t ninc = wave_scan_u32(ne);
+            const uint32_t Tn = (uint32_t)__builtin_amdgcn_readlane((int)ninc, 63);
+            lds_wave_sync();   // (every lane has read its entries of the list: it is overwritten in place)
             {
-                uint32_t pre = linc - lsum;
+                uint32_t pre = linc - lsum, slot = ninc - ne;
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k) {
-                    const uint32_t idx = (uint32_t)ln * Kp + (uint32_t)k;
-                    if ((uint32_t)k < Kp && idx < Tc) {
-                        plist[wv][idx] = make_uint2(er0[k], eown[k]);   // (the cell code is spent)
-                        ptab[wv][idx] = pre;
+                    if (elen[k]) {
+                        plist[wv][slot] = make_uint2(er0[k], eown[k]);
+                        ptab[wv][slot] = pre;
+                        ++slot;
                     }
                     pre += elen[k];
                 }
-                if (ln == 0) ptab[wv][Tc] = R;
+                if (ln < 4) ptab[wv][Tn + (uint32_t)ln] = R;   // sentinels: no record index reaches them
             }
             lds_wave_sync();
+            if (R != 0) {
             // lane ln tests records [ln C, ln C + C) of the concatenation, PUNR consecutive ones per trip
+            static_assert(PUNR == 3, "the trip's entry arithmetic below is written for three records");
             const uint32_t C = (R + 63u) / 64u;
             uint32_t i0 = (uint32_t)ln * C;
             const uint32_t iend = i0 + C < R ? i0 + C : R;
             uint32_t cur = 0;
             {
-                uint32_t hi = Tc;   // last entry whose offset is <= i0 (empty ranges share their offset with the next entry)
+                uint32_t hi = Tn;   // last entry whose offset is <= i0
                 while (hi - cur > 1) {
                     const uint32_t mid = (cur + hi) >> 1;
                     if (ptab[wv][mid] <= i0) cur = mid;
                     else hi = mid;
                 }
             }
-            uint2 ce = plist[wv][cur];
-            uint32_t cpre = ptab[wv][cur], cnext = ptab[wv][cur + 1];
+            uint32_t b0 = ptab[wv][cur];
             for (; __builtin_amdgcn_ballot_w64(i0 < iend) != 0; i0 += PUNR) {
+                // the three records of this trip lie in entries cur .. cur + 2, the first of the next trip in cur .. cur + 3
+                const uint32_t b1 = ptab[wv][cur + 1], b2 = ptab[wv][cur + 2], b3 = ptab[wv][cur + 3];
                 bool pass[PUNR];
                 uint32_t pos[PUNR], own[PUNR];
+                uint2 ent[PUNR];
+                uint32_t epre[PUNR];
+#pragma unroll
+                for (int u = 0; u < PUNR; ++u) {
+                    const uint32_t ii = i0 + (uint32_t)u;
+                    const uint32_t kk = (ii >= b1 ? 1u : 0u) + (ii >= b2 ? 1u : 0u);
+                    ent[u] = plist[wv][cur + kk];
+                    epre[u] = kk == 0u ? b0 : (kk == 1u ? b1 : b2);
+                }
 #pragma unroll
                 for (int u = 0; u < PUNR; ++u) {
                     const uint32_t ii = i0 + (uint32_t)u;
                     pass[u] = ii < iend;
-                    while (pass[u] && ii >= cnext) {   // (entries behind the last one do not exist: ii < R = the sentinel)
-                        ++cur;
-                        ce = plist[wv][cur];
-                        cpre = cnext;
-                        cnext = ptab[wv][cur + 1];
-                    }
-                    pos[u] = pass[u] ? ce.x + (ii - cpre) : 0u;
-                    own[u] = ce.y;
+                    pos[u] = pass[u] ? ent[u].x + (ii - epre[u]) : 0u;
+                    own[u] = pass[u] ? ent[u].y : 0u;
                 }
-                float4 rf[PUNR];
-#pragma unroll
-                for (int u = 0; u < PUNR; ++u) rf[u] = recs32[pos[u]];
+                {
+                    const uint32_t nx = i0 + (uint32_t)PUNR;
+                    const uint32_t kk = (nx >= b1 ? 1u : 0u) + (nx >= b2 ? 1u : 0u) + (nx >= b3 ? 1u : 0u);
+                    b0 = kk == 0u ? b0 : (kk == 1u ? b1 : (kk == 2u ? b2 : b3));
+                    cur = cur + kk < Tn ? cur + kk : Tn - 1u;   // (a lane past its share: nothing of it is used)
+                }
+                float4 rf[PUNR], oq[PUNR];
+                uint32_t osk[PUNR];
 #pragma unroll
                 for (int u = 0; u < PUNR; ++u) {
-                    const float4 oq = pq[wv][own[u]];
-                    const uint32_t osk = pskip[wv][own[u]];
-                    const float dx = rf[u].x - oq.x, dy = rf[u].y - oq.y;
+                    rf[u] = recs32[pos[u]];
+                    oq[u] = pq[wv][own[u]];
+                    osk[u] = pskip[wv][own[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < PUNR; ++u) {
+                    const float dx = rf[u].x - oq[u].x, dy = rf[u].y - oq[u].y;
                     float d = __builtin_fmaf(dy, dy, dx * dx);
                     if (DIM == 3) {
-                        const float dz = rf[u].z - oq.z;
+                        const float dz = rf[u].z - oq[u].z;
                         d = __builtin_fmaf(dz, dz, d);
                     }
-                    pass[u] = pass[u] && !(d > oq.w) && pos[u] != osk;
+                    pass[u] = (int)pass[u] & (int)!(d > oq[u].w) & (int)(pos[u] != osk[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < PUNR; ++u) {
@@ -1446,6 +1469,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     }
                     lds_wave_sync();
                 }
+            }
             }
             if (T <= (uint32_t)kPoolCap) break;   // (every mask is empty: no second scan to find that out)
         }
