@@ -1119,6 +1119,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 d = d + dz * dz;
             }
             e = sqrt(d);
+            // the hinted record is the first candidate as well (eval()'s arithmetic and test; the fused loop's hints are
+            // sorted positions): no second load of it behind the barrier
+            const int32_t id = (int32_t)__double_as_longlong(rc.w);
+            if (h < m && (d < best || (d == best && id < bi))) {
+                best = d;
+                bi = id;
+                bp = h;
+            }
         }
         __shared__ double ered[NW];
         const double w = wave_sum(e);
@@ -1208,7 +1216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
         }
     };
-    if (active && hint) {
+    if (!FUSED && active && hint) {
         const uint32_t h = (uint32_t)hint[q];
         if (h < m) {
             const uint32_t hp = pos_mode ? h : inv[h];
