@@ -150,10 +150,15 @@ def test_sharded_ops_single_process(rigid):
     np.testing.assert_allclose(hist, r["err_hist"].cpu().numpy()[:n], rtol=1e-9, atol=1e-9)
 
 
-@pytest.mark.parametrize("name", ["normal3", "uniform2", "clustered_outside", "lattice_ties"])
+@pytest.mark.parametrize("name", ["normal3", "uniform2", "clustered_outside", "lattice_ties", "below_float_resolution", "far_outliers",
+                                  "sheet", "far_origin"])
 def test_hint_does_not_change_the_result(rigid, name):
     """ICP_HINT_IDX: whatever indices come in -- the true answer, random targets, a constant,
-    out-of-range garbage -- the result is the same exact argmin (also with ICP_COMPARE_SQRT)."""
+    out-of-range garbage -- the result is the same exact argmin (also with ICP_COMPARE_SQRT).  Hinted argmin searches run
+    through grid_pool_kernel (the wave works the neighbour cells off together, fp32 pre-filter, fp64 candidates merged by
+    LDS atomics): good hints leave it nothing to merge, random ones make every ball large (lists of more than 384 cells:
+    several passes) and most records candidates; on the lattice every merge is a tie on d2 that the index decides; the
+    outliers and the far origin are beyond what the filter's floats can hold (stored as NaN / filter off)."""
     src, tgt = clouds()[name]
     n, m = len(src), len(tgt)
     rng = np.random.default_rng(5)
