@@ -1056,6 +1056,7 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 #define ICP_POOL_CAP 384
 #endif
 constexpr int kPoolCap = ICP_POOL_CAP;   // list entries per wave and compaction pass (more: another pass; 256 / 384 / 512: 177 / 169 / 170 us)
+constexpr int kPoolQ = 384;              // candidates queued per wave before they are evaluated (a trip adds at most 64 x 3)
 #ifndef ICP_POOL_UNR
 #define ICP_POOL_UNR 3                   // records per lane and trip of the wave-level walk (2 / 3 / 4 / 6: 169 / 169 / 169 / 185 us)
 #endif
@@ -1145,6 +1146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ float4 pq[NW][64];                      // owner's query in cell units and its threshold
     __shared__ uint32_t pskip[NW][64];                 // position of the owner's best record
     __shared__ double psrc[NW][DIM][64];               // owner's query
+    __shared__ uint2 pqueue[NW][kPoolQ];               // candidates waiting for their fp64 evaluation: (owner lane, position)
     __shared__ unsigned long long pbest[NW][64];       // owner's best d2 (bits)
     __shared__ uint32_t pid[NW][64], ppos[NW][64];     // its index and position
 #pragma unroll
@@ -1301,6 +1303,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         pbest[wv][ln] = mybits;
         pid[wv][ln] = (uint32_t)bi;
         ppos[wv][ln] = bp;
+        // fp64 evaluation of the queued candidates by whichever lane takes them (the owner's coordinates from LDS, eval()'s
+        // arithmetic: the same bits), 64 per round; one that cannot reach its owner's present best is dropped, the others are
+        // merged into the owners' slots: least d2, then least index among the records with that d2, then that record's position
+        uint32_t qcount = 0;   // (wave-uniform)
+        auto flush = [&]() {
+            lds_wave_sync();
+            for (uint32_t base = 0; base < qcount; base += 64) {
+                const uint32_t qi = base + (uint32_t)ln;
+                const bool have = qi < qcount;
+                const uint2 qe = pqueue[wv][have ? qi : 0u];
+                const int o = have ? (int)qe.x : 0;
+                unsigned long long db = ~0ull;
+                uint32_t id = 0x7fffffffu;
+                bool cand = false;
+                if (have) {
+                    const double4 rc = recs[qe.y];
+                    const double dx = rc.x - psrc[wv][0][o], dy = rc.y - psrc[wv][1][o];
+                    double d = dx * dx + dy * dy;
+                    if (DIM == 3) {
+                        const double dz = rc.z - psrc[wv][2][o];
+                        d = d + dz * dz;
+                    }
+                    id = (uint32_t)(int32_t)__double_as_longlong(rc.w);
+                    db = (unsigned long long)__double_as_longlong(d);
+                    cand = db <= pbest[wv][o];
+                }
+                if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
+                if (cand) atomicMin(&pbest[wv][o], db);
+                lds_wave_sync();
+                const unsigned long long nbits = pbest[wv][ln];
+                const bool chg = nbits != mybits;
+                if (chg) {   // a better d2 for this lane's own query: its old index no longer counts
+                    pid[wv][ln] = 0x7fffffffu;
+                    mybits = nbits;
+                }
+                lds_wave_sync();
+                const bool top = cand && db == pbest[wv][o];
+                if (top) atomicMin(&pid[wv][o], id);
+                lds_wave_sync();
+                if (top && id == pid[wv][o]) ppos[wv][o] = qe.y;
+                lds_wave_sync();
+                const uint32_t nid = pid[wv][ln];
+                if (chg || nid != (uint32_t)bi) {
+                    best = __longlong_as_double((long long)mybits);
+                    bi = (int32_t)nid;
+                    bp = ppos[wv][ln];
+                    refresh();
+                    pq[wv][ln].w = f_thr;
+                    pskip[wv][ln] = f_skip;
+                }
+                lds_wave_sync();
+            }
+            qcount = 0;
+        };
         // phase C: the wave's list of (cell, owner) pairs, worked off 64 at a time
         while (true) {
             const uint32_t cnt = (uint32_t)__builtin_popcount(mask);
@@ -1430,55 +1486,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     }
                     pass[u] = (int)pass[u] & (int)!(d > oq[u].w) & (int)(pos[u] != osk[u]);
                 }
+                // candidates the filter let through: queued (owner, position) -- slots from the ballots, no atomics -- and
+                // evaluated 64 at a time when the walk is over (or the queue nearly full)
 #pragma unroll
                 for (int u = 0; u < PUNR; ++u) {
-                    if (__builtin_amdgcn_ballot_w64(pass[u]) == 0) continue;
-                    // fp64 evaluation by the finder (a candidate that cannot reach the owner's present best is dropped at
-                    // once), then the merge into the owner's slot
-                    const int o = (int)own[u];
-                    unsigned long long db = ~0ull;
-                    uint32_t id = 0x7fffffffu;
-                    bool cand = false;
-                    if (pass[u]) {
-                        const double4 rc = recs[pos[u]];
-                        const double dx = rc.x - psrc[wv][0][o], dy = rc.y - psrc[wv][1][o];
-                        double d = dx * dx + dy * dy;
-                        if (DIM == 3) {
-                            const double dz = rc.z - psrc[wv][2][o];
-                            d = d + dz * dz;
-                        }
-                        id = (uint32_t)(int32_t)__double_as_longlong(rc.w);
-                        db = (unsigned long long)__double_as_longlong(d);
-                        cand = db <= pbest[wv][o];
-                    }
-                    if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
-                    if (cand) atomicMin(&pbest[wv][o], db);
-                    lds_wave_sync();
-                    const unsigned long long nbits = pbest[wv][ln];
-                    const bool chg = nbits != mybits;
-                    if (chg) {   // a better d2 for this lane's own query: its old index no longer counts
-                        pid[wv][ln] = 0x7fffffffu;
-                        mybits = nbits;
-                    }
-                    lds_wave_sync();
-                    const bool top = cand && db == pbest[wv][o];
-                    if (top) atomicMin(&pid[wv][o], id);
-                    lds_wave_sync();
-                    if (top && id == pid[wv][o]) ppos[wv][o] = pos[u];
-                    lds_wave_sync();
-                    const uint32_t nid = pid[wv][ln];
-                    if (chg || nid != (uint32_t)bi) {
-                        best = __longlong_as_double((long long)mybits);
-                        bi = (int32_t)nid;
-                        bp = ppos[wv][ln];
-                        refresh();
-                        pq[wv][ln].w = f_thr;
-                        pskip[wv][ln] = f_skip;
-                    }
-                    lds_wave_sync();
+                    const unsigned long long bm = __builtin_amdgcn_ballot_w64(pass[u]);
+                    if (bm == 0) continue;
+                    if (pass[u]) pqueue[wv][qcount + (uint32_t)__popcll(bm & ((1ull << ln) - 1ull))] = make_uint2(own[u], pos[u]);
+                    qcount += (uint32_t)__popcll(bm);
                 }
+                if (qcount > (uint32_t)(kPoolQ - 64 * PUNR)) flush();
             }
             }
+            if (qcount) flush();
             if (T <= (uint32_t)kPoolCap) break;   // (every mask is empty: no second scan to find that out)
         }
         lds_wave_sync();   // (before the slots are rewritten at the next level)
@@ -2872,8 +2892,8 @@ int grid_query(icp_ctx *ctx, const GridBuild &gb, const double *src, int64_t n, 
                                jump_env >= 0 ? jump_env : ((hint && pos_mode) ? 1 : 0), split_env, clb, csr, defer_max); \
         if (g_grid_events) (void)hipEventRecord(g_grid_events[2], st); \
     } while (0)
-    static const int pool_env = getenv("ICP_GRID_POOL") ? atoi(getenv("ICP_GRID_POOL")) : 1;   // (0: per-lane kernel everywhere; 2: the pool kernel for unhinted searches too)
-    const bool pool = pool_env != 0 && (hint || pool_env > 1) && !le && !coh && !g_grid_dbg && !list8;
+    static const int pool_env = getenv("ICP_GRID_POOL") ? atoi(getenv("ICP_GRID_POOL")) : 1;   // (0: per-lane kernel everywhere; 2: the pool kernel for hinted searches only)
+    const bool pool = pool_env != 0 && (hint || pool_env != 2) && !le && !coh && !g_grid_dbg && !list8;
     static const bool coh_trace = getenv("ICP_COHERENT_TRACE") != nullptr;
     // share of unproven rows beyond which an iteration takes the whole-cloud search (ICP_COHERENT_LIMIT, default 0.12)
     static const double coh_frac = getenv("ICP_COHERENT_LIMIT") ? atof(getenv("ICP_COHERENT_LIMIT")) : 0.12;
