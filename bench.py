@@ -443,8 +443,8 @@ def main():
     if args.brute:
         t_kernel = t_brute
     else:
-        # the search as iterations 2..K of the loop run it (previous answer as the hint: grid_pool_kernel), and the first
-        # iteration's (no hint: grid_query_kernel)
+        # the search as iterations 2..K of the loop run it (previous answer as the hint), and the first iteration's (no hint);
+        # both through grid_pool_kernel
         t_kernel, t_lane, t_defer = rigid.time_grid_query(src_d, tgt_d, reps=max(3, min(K, 10)), ctx=ctx, parts=True, hinted=True)
         t_first, t_first_lane, t_first_defer = rigid.time_grid_query(src_d, tgt_d, reps=max(3, min(K, 10)), ctx=ctx, parts=True)
     brute_roof = None
@@ -469,9 +469,9 @@ def main():
                 "kernel": "grid search as iterations 2..K run it (previous match as the hint) = grid_pool_kernel<3> + "
                           "grid_defer_kernel<3,false,false>", "kernel_ms": t_kernel * 1e3,
                 "kernel_ms_parts": {"grid_pool_kernel": t_lane * 1e3, "grid_defer_kernel": t_defer * 1e3},
-                "first_iteration": {"kernel": "grid_query_kernel<3,false,256,4,false,4,3> + grid_defer_kernel (no hint)",
+                "first_iteration": {"kernel": "grid_pool_kernel<3> + grid_defer_kernel (no hint)",
                                     "kernel_ms": t_first * 1e3,
-                                    "kernel_ms_parts": {"grid_query_kernel": t_first_lane * 1e3, "grid_defer_kernel": t_first_defer * 1e3},
+                                    "kernel_ms_parts": {"grid_pool_kernel": t_first_lane * 1e3, "grid_defer_kernel": t_first_defer * 1e3},
                                     "achieved": gbytes / t_first / 1e9, "frac": gbytes / t_first / 1e9 / HBM_PEAK_GBS},
                 "note": "exact grid search (two launches: the wave-cooperative pass, then one half-wave per deferred query): "
                         "algorithmic bytes per search = 24 B/query + 4 B/index out + 32 B/target record (Morton-sorted, read at "

@@ -122,8 +122,8 @@ def time_grid_query(source, target, reps=5, ctx=None, parts=False, hinted=False)
     """Average duration (s) of one grid search as it runs inside icp_rigid_run: target grid
     prebuilt, queries in Morton order.  Measured with HIP events on the launch stream
     (bench.py's roofline leg).  parts=True: (whole search, per-lane kernel, grid_defer_kernel).
-    hinted=True: the search with the previous answer as its hint (iterations 2.. of a loop:
-    grid_pool_kernel); False: without (the first iteration: grid_query_kernel)."""
+    hinted=True: the search with the previous answer as its hint (iterations 2.. of a loop);
+    False: without (the first iteration).  Both run grid_pool_kernel."""
     ctx = ctx or get_context()
     torch = ctx.torch
     src, tgt, dim = _dims(ctx, source, target)

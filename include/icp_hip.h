@@ -221,10 +221,9 @@ int icp_rigid_run_dist(icp_ctx *ctx, const double *src_local, int64_t n_local, c
 /* Measurement hook (no counterpart in the reference): builds the target grid and the Morton
  * order of the queries exactly as icp_rigid_run does, then times `reps` grid searches with HIP
  * events on the context's stream.  ms_out_dev[6] = average milliseconds of {one whole search,
- * its per-lane kernel (grid_query_kernel), its wave-per-query kernel for the deferred queries
+ * its first kernel (grid_pool_kernel), its second kernel for the deferred queries
  * (grid_defer_kernel)} without hints -- the first iteration of a loop -- and of the same three
- * with the previous answer as the hint, as every later iteration runs it (grid_pool_kernel +
- * grid_defer_kernel).  Synchronises. */
+ * with the previous answer as the hint, as every later iteration runs it.  Synchronises. */
 int icp_bench_grid_query(icp_ctx *ctx, const double *src, int64_t n, const double *tgt, int64_t m, int dim,
                          int reps, double *ms_out_dev);
 

@@ -31,21 +31,20 @@ def main(root, stats):
         name, rest = ln[:110], ln[110:].split()
         dur[name.strip()] = float(rest[2]) * 1e-3          # average, microseconds
     pick = lambda frag: [k for k in c if frag in k]
-    nohint = [k for k in pick("grid_query_kernel") if "4, false, 4, 3, false, 0>" in k][0]
     loop = [k for k in pick("grid_pool_kernel") if "<3, true>" in k][0]
-    hinted = [k for k in pick("grid_pool_kernel") if "<3, false>" in k][0]     # what bench.py's roofline leg times
+    hinted = [k for k in pick("grid_pool_kernel") if "<3, false>" in k][0]     # hinted and unhinted searches of bench.py's roofline leg, averaged
     defer = [k for k in pick("grid_defer_kernel") if "false, false>" in k][0]
     us = lambda k: [v for n, v in dur.items() if k[:100].startswith(n[:100]) or n[:100].startswith(k[:100])][0]
     bytes_of = lambda k: 2.0 * c[k]["FETCH_SIZE"] * 1024 + c[k]["WRITE_SIZE"] * 1024
     cyc = us(loop) * 1e3 * CLOCK_GHZ
     out = {
-        "kernel": "grid search = grid_pool_kernel + grid_defer_kernel (previous answer as the hint: what bench.py's roofline leg times)",
+        "kernel": "grid search = grid_pool_kernel + grid_defer_kernel (bench.py's roofline leg; the counters average over its hinted and "
+                  "unhinted searches, which share the kernel symbol; in_loop_with_hints_fused is the hinted search inside the loop alone)",
         "workload": "2^20 x 2^20 (C2)",
         "fetch_size_kb": {"grid_pool_kernel": c[hinted]["FETCH_SIZE"], "grid_defer_kernel": c[defer]["FETCH_SIZE"]},
         "fetch_correction": 2.0,
         "write_size_kb": {"grid_pool_kernel": c[hinted]["WRITE_SIZE"], "grid_defer_kernel": c[defer]["WRITE_SIZE"]},
         "traffic_bytes": bytes_of(hinted) + bytes_of(defer),
-        "first_iteration_no_hints": {"traffic_bytes": bytes_of(nohint) + bytes_of(defer), "kernel_us": us(nohint)},
         "in_loop_with_hints_fused": {"traffic_bytes": bytes_of(loop) + bytes_of(defer), "kernel_us": us(loop), "defer_us": us(defer)},
         "valu_busy": c[loop]["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cyc,
         "ta_busy": c[loop]["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / cyc,
