@@ -1050,8 +1050,8 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 // A record the filter cannot reject is evaluated in fp64 by the lane that found it, with the owner's coordinates and
 // eval()'s arithmetic, and merged into the owner's slot by LDS atomics in three steps: least d2 (as bits: d2 >= 0), least
 // index among the records with that d2, position of that record -- the (d2, index) order of the full scan whatever the
-// order of arrival.  The owner then renews its threshold.  Lanes whose own query is finished, deferred or out of range keep
-// serving the others.  Own cell, hint, levels, gap test and hand-over to the deferred pass are those of grid_query_kernel.
+// order of arrival (the candidates of a walk are queued and merged 64 at a time when it is over).  The owner then renews its
+// threshold.  Lanes whose own query is finished, deferred or out of range keep serving the others.  Own cell, hint, levels, gap test and hand-over to the deferred pass are those of grid_query_kernel.
 #ifndef ICP_POOL_CAP
 #define ICP_POOL_CAP 384
 #endif
@@ -1274,7 +1274,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 g2[a][o] = __double2float_rd(g * g) * (1.0f - 0x1p-21f);
             }
         }
-        if (active) {   // phase A: the query's own cell, per lane (in the list it costs more: its records improve most bests, one merge each)
+        if (active) {   // phase A: the query's own cell, per lane (listed with the neighbours it gains 8 % where the hints are exact and nothing in
+                        // the ICP loop; an unhinted query would list all 27 cells and queue every record of them: 0.58 against 0.13 ms)
             uint32_t code = sp[0][1] | sp[1][1];
             if (DIM == 3) code |= sp[2][1];
             own_scan(start[(uint64_t)code << (DIM * l)], start[((uint64_t)code + 1) << (DIM * l)]);
