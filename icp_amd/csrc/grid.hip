@@ -1248,6 +1248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 deferred_q = true;
             }
         }
+        if (l >= cap && __builtin_amdgcn_ballot_w64(active) == 0) break;   // (everything left was handed over: no set-up for nobody)
         const double hl = gp.h * (double)(1 << l);
         const int ncl = 1 << (gp.bits - l);
         const double slack_h = hl * 0x1p-20;
